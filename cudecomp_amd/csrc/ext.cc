@@ -1,0 +1,169 @@
+// ext.cc -- cudecomp_ext.h: plan introspection and a single-move kernel entry for test harnesses.
+#include <cstring>
+#include <iostream>
+
+#include "cudecomp_ext.h"
+#include "errors.h"
+#include "internal.h"
+
+using namespace cudecomp;
+
+namespace {
+
+cudecompResult_t fail(const Error& e) {
+  std::cerr << e.what();
+  return e.code();
+}
+
+void exportMove(const Move3D& m, cudecompExtMove_t* o) {
+  o->src_buf = m.src_buf;
+  o->dst_buf = m.dst_buf;
+  o->src_off = m.src_off;
+  o->dst_off = m.dst_off;
+  for (int i = 0; i < 3; ++i) {
+    o->extent[i] = m.extent[i];
+    o->ss[i] = m.ss[i];
+    o->ds[i] = m.ds[i];
+  }
+  o->peer = m.peer;
+  o->reserved = 0;
+}
+
+bool peerTransposeBackend(cudecompTransposeCommBackend_t b) {
+#ifdef CUDECOMP_WITH_MPI
+  return transposeBackendIsPeer(b);
+#else
+  return !transposeBackendIsRccl(b);
+#endif
+}
+bool peerHaloBackend(cudecompHaloCommBackend_t b) {
+#ifdef CUDECOMP_WITH_MPI
+  return haloBackendIsPeer(b);
+#else
+  return !haloBackendIsRccl(b);
+#endif
+}
+
+}  // namespace
+
+extern "C" {
+
+cudecompResult_t cudecompExtGetTransposePlan(cudecompHandle_t handle, cudecompGridDesc_t gd, int32_t op,
+                                             const int32_t in_halo[], const int32_t out_halo[], const int32_t in_pad[],
+                                             const int32_t out_pad[], bool inplace, int32_t backend_override,
+                                             cudecompExtTransposePlan_t* out) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    if (!gd || !gd->initialized || gd->handle != handle) CD_INVALID_USAGE("invalid grid descriptor");
+    if (!out) CD_INVALID_USAGE("plan argument cannot be null");
+    if (op < 0 || op > 3) CD_INVALID_USAGE("op out of range");
+    const auto backend =
+        backend_override ? (cudecompTransposeCommBackend_t)backend_override : gd->config.transpose_comm_backend;
+    TransportTraits traits;
+    traits.pipelined = transposeBackendIsPipelined(backend);
+    traits.symmetric_recv = peerTransposeBackend(backend);
+    const CommAxis ca = (op == OP_X_TO_Y || op == OP_Y_TO_X) ? COMM_COL : COMM_ROW;
+    const cudecompCommInfo& ci = gd->comm(ca);
+    const TransposePlan p = buildTransposePlan(gd->shape, handle->rank, (TransposeOp)op, in_halo, out_halo, in_pad,
+                                               out_pad, inplace, traits, ci.npergroup);
+    if (p.nranks > CUDECOMP_EXT_MAX_MEMBERS) CD_NOT_SUPPORTED("communicator too large for cudecompExtTransposePlan_t");
+    std::memset(out, 0, sizeof(*out));
+    out->noop = p.noop;
+    out->exchange = p.exchange;
+    out->comm_axis = p.comm_axis;
+    out->nranks = p.nranks;
+    out->comm_rank = p.comm_rank;
+    out->send_buf = p.send_buf;
+    out->recv_buf = p.recv_buf;
+    out->send_base = p.send_base;
+    out->recv_base = p.recv_base;
+    out->n_pack = (int32_t)p.pack.size();
+    out->n_unpack = (int32_t)p.unpack.size();
+    for (int i = 0; i < p.nranks; ++i) {
+      out->member_global_rank[i] = ci.global_ranks[i];
+      if (p.exchange) {
+        out->send_cnt[i] = p.send_cnt[i];
+        out->send_off[i] = p.send_off[i];
+        out->recv_cnt[i] = p.recv_cnt[i];
+        out->recv_off[i] = p.recv_off[i];
+        out->remote_recv_off[i] = p.remote_recv_off[i];
+      }
+      out->schedule_dst[i] = p.schedule_dst[i];
+    }
+    for (size_t i = 0; i < p.pack.size(); ++i) exportMove(p.pack[i], &out->pack[i]);
+    for (size_t i = 0; i < p.unpack.size(); ++i) exportMove(p.unpack[i], &out->unpack[i]);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtGetHaloPlan(cudecompHandle_t handle, cudecompGridDesc_t gd, int32_t axis,
+                                        const int32_t halo[], const bool periods[], int32_t dim, const int32_t pad[],
+                                        int32_t backend_override, cudecompExtHaloPlan_t* out) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    if (!gd || !gd->initialized || gd->handle != handle) CD_INVALID_USAGE("invalid grid descriptor");
+    if (!out || !halo) CD_INVALID_USAGE("null argument");
+    if (axis < 0 || axis > 2 || dim < 0 || dim > 2) CD_INVALID_USAGE("axis/dim out of range");
+    const auto backend = backend_override ? (cudecompHaloCommBackend_t)backend_override : gd->config.halo_comm_backend;
+    const int32_t zero[3] = {0, 0, 0};
+    const HaloPlan p = buildHaloPlan(gd->shape, handle->rank, axis, dim, halo, periods, pad ? pad : zero,
+                                     peerHaloBackend(backend));
+    std::memset(out, 0, sizeof(*out));
+    out->kind = (int32_t)p.kind;
+    out->comm_axis = p.comm_axis;
+    out->xbuf = p.xbuf;
+    out->face_elements = p.face_elements;
+    for (int i = 0; i < 2; ++i) {
+      out->neighbor[i] = p.neighbor[i];
+      out->send_off[i] = p.send_off[i];
+      out->recv_off[i] = p.recv_off[i];
+    }
+    out->n_pre = (int32_t)p.pre.size();
+    out->n_post = (int32_t)p.post.size();
+    for (size_t i = 0; i < p.pre.size(); ++i) exportMove(p.pre[i], &out->pre[i]);
+    for (size_t i = 0; i < p.post.size(); ++i) exportMove(p.post[i], &out->post[i]);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const int64_t extent[3],
+                                   const int64_t ss[3], const int64_t ds[3], int32_t force_generic,
+                                   int32_t* kernel_class, hipStream_t stream) {
+  try {
+    if (!src || !dst || !extent || !ss || !ds) CD_INVALID_USAGE("null argument");
+    if (es != 4 && es != 8 && es != 16) CD_INVALID_USAGE("element size must be 4, 8 or 16");
+    Move3D m;
+    m.src_buf = BUF_IN;
+    m.dst_buf = BUF_OUT;
+    for (int i = 0; i < 3; ++i) {
+      m.extent[i] = extent[i];
+      m.ss[i] = ss[i];
+      m.ds[i] = ds[i];
+    }
+    void* bufs[3] = {const_cast<void*>(src), dst, nullptr};
+    KernelTuning t;
+    if (force_generic) t.force_class = MOVE_GENERIC;
+    KernelStats st;
+    launchMoves(&m, 1, bufs, es, stream, &t, &st);
+    if (kernel_class) {
+      *kernel_class = -1;
+      for (int c = 0; c < MOVE_CLASS_COUNT; ++c)
+        if (st.launches[c]) *kernel_class = c;
+    }
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+}  // extern "C"

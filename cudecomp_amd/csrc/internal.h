@@ -1,0 +1,136 @@
+// internal.h -- the two opaque objects of the C API and the pieces they own.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "bootstrap.h"
+#include "cudecomp.h"
+#include "decomp.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace cudecomp {
+class RcclContext;  // transport_rccl.cc
+class PeerContext;  // transport_peer.cc
+}  // namespace cudecomp
+
+// One row or column of the process grid as seen by this rank.
+struct cudecompCommInfo {
+  int rank = 0, nranks = 0;
+  int ngroups = 1, npergroup = 1;           // fast-interconnect groups (hosts) inside the communicator
+  std::vector<int> global_ranks;            // member -> rank in the handle's communicator
+  std::unique_ptr<cudecomp::Bootstrap> boot;  // control-plane communicator of the members
+};
+
+struct cudecompHandle {
+  bool initialized = false;
+  int rank = 0, nranks = 1;
+  int local_rank = 0, local_nranks = 1;
+  std::unique_ptr<cudecomp::Bootstrap> boot;
+  std::vector<std::string> hostnames;  // by rank
+  std::vector<int> rank_to_local_rank;
+
+  // device (probed lazily so that geometry queries also work on a machine without a GPU)
+  bool device_probed = false;
+  int device = -1;
+  int num_cus = 0;
+  std::vector<hipStream_t> streams;  // side streams for pipelined transports
+
+  std::shared_ptr<cudecomp::RcclContext> rccl;  // RCCL communicator over all ranks (created on demand)
+  std::shared_ptr<cudecomp::PeerContext> peer;  // xGMI / IPC peer-mapping registry (created on demand)
+
+  // environment switches (same names as the reference, docs/env_vars.rst)
+  bool graphs_enable = false;
+  bool performance_report_enable = false;
+  bool col_major_env_warned = false;
+
+  cudecomp::KernelTuning tuning;
+
+  ~cudecompHandle();
+};
+
+struct cudecompGridDesc {
+  bool initialized = false;
+  cudecompHandle_t handle = nullptr;
+  cudecompGridDescConfig_t config{};
+  bool gdims_dist_set = false;
+  bool mem_order_set = false;
+
+  cudecomp::GridShape shape;
+  std::array<int32_t, 2> pidx{};
+  cudecompCommInfo row, col;
+
+  std::vector<hipEvent_t> events;  // one per communicator member, for per-peer pipelining
+
+  // plan caches (key: op, halos, padding, in-place flag, transport traits)
+  using TransposeKey = std::tuple<int, std::array<int32_t, 12>, bool, bool, bool>;
+  std::map<TransposeKey, cudecomp::TransposePlan> transpose_plans;
+  using HaloKey = std::tuple<int, int, std::array<int32_t, 6>, std::array<bool, 3>, bool>;
+  std::map<HaloKey, cudecomp::HaloPlan> halo_plans;
+
+  cudecompCommInfo& comm(cudecomp::CommAxis a) { return a == cudecomp::COMM_ROW ? row : col; }
+  ~cudecompGridDesc();
+};
+
+namespace cudecomp {
+
+void ensureDevice(cudecompHandle_t handle);  // throws if no HIP device is usable
+void buildCommInfo(cudecompHandle_t handle, cudecompGridDesc_t gd);
+void resetCommInfo(cudecompGridDesc_t gd);
+
+inline int elementSize(cudecompDataType_t dtype) {
+  switch (dtype) {
+    case CUDECOMP_FLOAT: return 4;
+    case CUDECOMP_DOUBLE:
+    case CUDECOMP_FLOAT_COMPLEX: return 8;
+    default: return 16;
+  }
+}
+
+inline bool transposeBackendIsMpi(cudecompTransposeCommBackend_t b) {
+  return b == CUDECOMP_TRANSPOSE_COMM_MPI_P2P || b == CUDECOMP_TRANSPOSE_COMM_MPI_P2P_PL ||
+         b == CUDECOMP_TRANSPOSE_COMM_MPI_A2A;
+}
+inline bool transposeBackendIsRccl(cudecompTransposeCommBackend_t b) {
+  return b == CUDECOMP_TRANSPOSE_COMM_NCCL || b == CUDECOMP_TRANSPOSE_COMM_NCCL_PL;
+}
+inline bool transposeBackendIsPeer(cudecompTransposeCommBackend_t b) {
+  return b == CUDECOMP_TRANSPOSE_COMM_NVSHMEM || b == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_PL ||
+         b == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_SM;
+}
+inline bool transposeBackendIsPipelined(cudecompTransposeCommBackend_t b) {
+  return b == CUDECOMP_TRANSPOSE_COMM_MPI_P2P_PL || b == CUDECOMP_TRANSPOSE_COMM_NCCL_PL ||
+         b == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_PL;
+}
+inline bool haloBackendIsMpi(cudecompHaloCommBackend_t b) {
+  return b == CUDECOMP_HALO_COMM_MPI || b == CUDECOMP_HALO_COMM_MPI_BLOCKING;
+}
+inline bool haloBackendIsRccl(cudecompHaloCommBackend_t b) { return b == CUDECOMP_HALO_COMM_NCCL; }
+inline bool haloBackendIsPeer(cudecompHaloCommBackend_t b) {
+  return b == CUDECOMP_HALO_COMM_NVSHMEM || b == CUDECOMP_HALO_COMM_NVSHMEM_BLOCKING;
+}
+
+// executors
+void runTranspose(cudecompHandle_t handle, cudecompGridDesc_t gd, TransposeOp op, void* input, void* output, void* work,
+                  cudecompDataType_t dtype, const int32_t* in_halo, const int32_t* out_halo, const int32_t* in_pad,
+                  const int32_t* out_pad, hipStream_t stream);
+void runHalo(cudecompHandle_t handle, cudecompGridDesc_t gd, int axis, void* input, void* work,
+             cudecompDataType_t dtype, const int32_t* halo, const bool* periods, int dim, const int32_t* pad,
+             hipStream_t stream);
+
+// autotune.cc
+void autotuneTranspose(cudecompHandle_t handle, cudecompGridDesc_t gd, const cudecompGridDescAutotuneOptions_t* opt,
+                       bool autotune_backend, bool autotune_pdims);
+void autotuneHalo(cudecompHandle_t handle, cudecompGridDesc_t gd, const cudecompGridDescAutotuneOptions_t* opt,
+                  bool autotune_backend, bool autotune_pdims);
+std::vector<cudecompTransposeCommBackend_t> transposeBackendCandidates(const cudecompGridDescAutotuneOptions_t* opt);
+std::vector<cudecompHaloCommBackend_t> haloBackendCandidates(const cudecompGridDescAutotuneOptions_t* opt);
+std::vector<std::array<int32_t, 2>> pdimCandidates(int nranks, bool col_major);
+
+}  // namespace cudecomp

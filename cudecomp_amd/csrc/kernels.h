@@ -1,0 +1,32 @@
+// kernels.h -- host entry points of the HIP data-movement kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "plan.h"
+
+namespace cudecomp {
+
+// How a normalized move is executed on the GPU.
+enum MoveClass {
+  MOVE_ROWS_VEC = 0,   // rows contiguous on both sides, everything 16-byte aligned: 16 B/lane streaming copy
+  MOVE_TRANSPOSE = 1,  // fastest source dim != fastest destination dim: LDS-tiled transpose (vector or scalar lanes)
+  MOVE_GENERIC = 2,    // anything else (odd extents, unaligned bases, degenerate dims): element-wise
+  MOVE_CLASS_COUNT = 3
+};
+
+struct KernelStats {  // filled per launch when requested (tests, bench bookkeeping)
+  int launches[MOVE_CLASS_COUNT] = {0, 0, 0};
+  i64 elements[MOVE_CLASS_COUNT] = {0, 0, 0};
+};
+
+struct KernelTuning {
+  int transpose_tile_log2 = 0;  // 0 = default
+  int force_class = -1;         // tests: force MOVE_GENERIC (2) to cross-check the fast paths
+};
+
+// Execute `n` independent moves (disjoint destinations) of `es`-byte elements.  bufs[BufId] are the
+// device pointers of the input / output / workspace buffers.  Asynchronous on `stream`.
+void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStream_t stream,
+                 const KernelTuning* tuning = nullptr, KernelStats* stats = nullptr);
+
+}  // namespace cudecomp

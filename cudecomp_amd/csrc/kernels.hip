@@ -1,0 +1,407 @@
+// kernels.hip -- hand-written gfx950 (CDNA4 / MI355X) data-movement kernels.
+//
+// These replace the two device code paths of NVIDIA/cuDecomp's local phases:
+//   * the batched strided 3-D copy kernel (reference include/internal/cudecomp_kernels.cuh:125-180:
+//     one element per thread per iteration, two 64-bit div/mod pairs per element, no vector access);
+//   * cutensorPermute, the closed-source 3-D permutation (reference include/internal/transpose.h:80-157).
+// Here both are one object, a Move3D (plan.h), executed by one of three kernels:
+//
+//   rows_kernel<VB>       fastest dim contiguous on both sides.  Each lane moves VB = 16 (8, 4) bytes,
+//                         a 256-thread workgroup keeps 4 vectors per lane (16 KiB) in flight, lanes run
+//                         along the row so that every wavefront touches 1 KiB contiguous segments.
+//                         No per-element index math: one (row, plane) decode per WORKGROUP.
+//   transpose_kernel      fastest source dim != fastest destination dim.  A TI x TJ element tile is
+//                         staged through LDS: global reads are coalesced along the source-fast dim,
+//                         global writes along the destination-fast dim, both at 16 B/lane when the
+//                         addresses allow (VW elements per lane), element-wise otherwise.  The third
+//                         dim is a batch index.  All 5 non-identity 3-D permutations with arbitrary
+//                         (halo-padded, per-peer sub-block) strides reduce to this or to rows_kernel.
+//   generic_kernel<ES>    degenerate shapes (no unit stride on one side, 1-element rows).
+//
+// This is pure data movement: no MFMA; the bound is HBM (8 TB/s spec, ~6.3 TB/s achievable copy rate).
+// Up to kMaxBatch moves (e.g. the per-peer pack copies of one transpose) share one launch; the
+// descriptors travel in the kernel argument segment.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "errors.h"
+#include "kernels.h"
+
+namespace cudecomp {
+
+namespace {
+
+constexpr int kMaxBatch = 8;
+constexpr int kThreads = 256;
+constexpr int kRowsUnroll = 4;
+
+struct DevMove {
+  const char* src;
+  char* dst;
+  long long e[3];   // extents   (units depend on the kernel, see the launchers)
+  long long ss[3];  // src strides
+  long long ds[3];  // dst strides
+};
+
+struct Batch {
+  int n;
+  int p0[kMaxBatch];                      // kernel-specific small parameter
+  unsigned int first_block[kMaxBatch + 1];
+  unsigned int t0[kMaxBatch];             // tiles along dim 0
+  unsigned int t1[kMaxBatch];             // tiles along dim 1
+  DevMove m[kMaxBatch];
+};
+
+// N-byte lane payloads as native vector types (kept in VGPRs; a struct-of-array payload gets
+// "promoted" to LDS by the compiler, which costs occupancy and LDS bandwidth).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int N> struct BytesOf;
+template <> struct BytesOf<4> { using type = unsigned int; };
+template <> struct BytesOf<8> { using type = u32x2; };
+template <> struct BytesOf<16> { using type = u32x4; };
+template <int N> using Bytes = typename BytesOf<N>::type;
+
+// element v (ES bytes) of a VW-element vector
+template <int ES, int VW> struct Lane;
+template <int ES> struct Lane<ES, 1> {
+  static __device__ __forceinline__ Bytes<ES> get(const Bytes<ES>& x, int) { return x; }
+  static __device__ __forceinline__ void set(Bytes<ES>& x, int, const Bytes<ES>& e) { x = e; }
+};
+template <> struct Lane<4, 4> {
+  static __device__ __forceinline__ unsigned int get(const u32x4& x, int v) { return x[v]; }
+  static __device__ __forceinline__ void set(u32x4& x, int v, unsigned int e) { x[v] = e; }
+};
+template <> struct Lane<4, 2> {
+  static __device__ __forceinline__ unsigned int get(const u32x2& x, int v) { return x[v]; }
+  static __device__ __forceinline__ void set(u32x2& x, int v, unsigned int e) { x[v] = e; }
+};
+template <> struct Lane<8, 2> {
+  static __device__ __forceinline__ u32x2 get(const u32x4& x, int v) { return v == 0 ? x.xy : x.zw; }
+  static __device__ __forceinline__ void set(u32x4& x, int v, const u32x2& e) {
+    if (v == 0) x.xy = e; else x.zw = e;
+  }
+};
+
+__device__ __forceinline__ int findMove(const Batch& b, unsigned int block) {
+  int mi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxBatch; ++i)
+    if (i < b.n && block >= b.first_block[i]) mi = i;
+  return mi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows_kernel: e[0] = vectors per row, e[1] = rows, e[2] = planes; ss/ds[1], [2] in vectors.
+// p0 = log2(lanes per row).  A workgroup covers (256 >> p0) * kRowsUnroll rows x (1 << p0) vectors.
+// ---------------------------------------------------------------------------------------------
+template <int VB>
+__global__ __launch_bounds__(kThreads) void rows_kernel(const Batch b) {
+  using V = Bytes<VB>;
+  const int mi = findMove(b, blockIdx.x);
+  const DevMove& m = b.m[mi];
+  const unsigned int lb = blockIdx.x - b.first_block[mi];
+  const int lg = b.p0[mi];
+  const int lpr = 1 << lg;
+  const int rb = kThreads >> lg;
+  const unsigned int tc = b.t0[mi], tr = b.t1[mi];
+  const unsigned int bc = lb % tc;
+  const unsigned int rest = lb / tc;
+  const unsigned int br = rest % tr;
+  const long long plane = rest / tr;
+
+  const long long col = (long long)bc * lpr + (threadIdx.x & (lpr - 1));
+  const long long r0 = (long long)br * rb * kRowsUnroll + (threadIdx.x >> lg);
+  if (col >= m.e[0]) return;
+  const V* __restrict__ s = reinterpret_cast<const V*>(m.src) + plane * m.ss[2] + col;
+  V* __restrict__ d = reinterpret_cast<V*>(m.dst) + plane * m.ds[2] + col;
+
+  V v[kRowsUnroll];
+#pragma unroll
+  for (int u = 0; u < kRowsUnroll; ++u) {
+    const long long r = r0 + (long long)u * rb;
+    if (r < m.e[1]) v[u] = s[r * m.ss[1]];
+  }
+#pragma unroll
+  for (int u = 0; u < kRowsUnroll; ++u) {
+    const long long r = r0 + (long long)u * rb;
+    if (r < m.e[1]) d[r * m.ds[1]] = v[u];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// transpose_kernel: dims (i, j, k): i is unit-stride in the source, j is unit-stride in the
+// destination, k is the batch dim.  e = {ei, ej, ek}; ss = {1, sj, sk}; ds = {di, 1, dk} (elements).
+// ---------------------------------------------------------------------------------------------
+template <int ES, int VW, int TI, int TJ>
+__global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
+  using E = Bytes<ES>;
+  using V = Bytes<ES * VW>;
+  constexpr int TPR = TI / VW;          // lanes per source row segment
+  constexpr int RPP = kThreads / TPR;   // source rows per pass
+  constexpr int NP = TJ / RPP;          // load passes
+  constexpr int TPO = TJ / VW;          // lanes per destination row segment
+  constexpr int RPO = kThreads / TPO;   // destination rows per pass
+  constexpr int NPO = TI / RPO;         // store passes
+  constexpr int PITCH = TI + 1;         // LDS row pitch in elements: +1 keeps column reads <= 2-way conflicted
+  static_assert(TI % VW == 0 && TJ % VW == 0, "tile must hold whole vectors");
+  static_assert(kThreads % TPR == 0 && TJ % RPP == 0, "load mapping");
+  static_assert(kThreads % TPO == 0 && TI % RPO == 0, "store mapping");
+
+  __shared__ E tile[TJ * PITCH];
+
+  const int mi = findMove(b, blockIdx.x);
+  const DevMove& m = b.m[mi];
+  const unsigned int lb = blockIdx.x - b.first_block[mi];
+  const unsigned int ti_n = b.t0[mi], tj_n = b.t1[mi];
+  const unsigned int bi = lb % ti_n;
+  const unsigned int rest = lb / ti_n;
+  const unsigned int bj = rest % tj_n;
+  const long long k = rest / tj_n;
+
+  const long long i0 = (long long)bi * TI, j0 = (long long)bj * TJ;
+  const long long ei = m.e[0], ej = m.e[1];
+  const long long sj = m.ss[1], sk = m.ss[2], di = m.ds[0], dk = m.ds[2];
+  const E* __restrict__ src = reinterpret_cast<const E*>(m.src) + k * sk;
+  E* __restrict__ dst = reinterpret_cast<E*>(m.dst) + k * dk;
+  const int tid = threadIdx.x;
+
+  // ---- global -> registers (all loads issued before the first use) -> LDS, rows along i
+  {
+    const int li = (tid % TPR) * VW;
+    const int lj = tid / TPR;
+    V regs[NP] = {};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const long long j = j0 + lj + p * RPP;
+      if (i0 + li < ei && j < ej) regs[p] = *reinterpret_cast<const V*>(src + j * sj + i0 + li);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int jj = lj + p * RPP;
+      E* row = tile + jj * PITCH + li;
+#pragma unroll
+      for (int v = 0; v < VW; ++v) row[v] = Lane<ES, VW>::get(regs[p], v);
+    }
+  }
+  __syncthreads();
+  // ---- LDS -> registers -> global, rows along j
+  {
+    const int lj = (tid % TPO) * VW;
+    const int li = tid / TPO;
+#pragma unroll
+    for (int p = 0; p < NPO; ++p) {
+      const int ii = li + p * RPO;
+      const long long i = i0 + ii;
+      if (i < ei && j0 + lj < ej) {
+        V out;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) Lane<ES, VW>::set(out, v, tile[(lj + v) * PITCH + ii]);
+        *reinterpret_cast<V*>(dst + i * di + j0 + lj) = out;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic_kernel: element-wise, lanes along dim p0 (the destination-fast dim when there is one).
+// ---------------------------------------------------------------------------------------------
+template <int ES>
+__global__ __launch_bounds__(kThreads) void generic_kernel(const Batch b) {
+  using E = Bytes<ES>;
+  const int mi = findMove(b, blockIdx.x);
+  const DevMove& m = b.m[mi];
+  const unsigned int lb = blockIdx.x - b.first_block[mi];
+  const unsigned int nb = b.first_block[mi + 1] - b.first_block[mi];
+  const int f = b.p0[mi], g = (f + 1) % 3, h = (f + 2) % 3;
+  const unsigned long long ef = m.e[f], eg = m.e[g];
+  const unsigned long long total = ef * eg * (unsigned long long)m.e[h];
+  const E* __restrict__ src = reinterpret_cast<const E*>(m.src);
+  E* __restrict__ dst = reinterpret_cast<E*>(m.dst);
+  for (unsigned long long n = (unsigned long long)lb * kThreads + threadIdx.x; n < total;
+       n += (unsigned long long)nb * kThreads) {
+    const unsigned long long kf = n % ef, t = n / ef;
+    const unsigned long long kg = t % eg, kh = t / eg;
+    dst[kf * m.ds[f] + kg * m.ds[g] + kh * m.ds[h]] = src[kf * m.ss[f] + kg * m.ss[g] + kh * m.ss[h]];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct Classified {
+  MoveClass cls;
+  int variant;  // rows: vector bytes; transpose: elements per vector
+  DevMove dm;
+  int p0;
+  unsigned int t0, t1;
+  unsigned long long blocks;
+  i64 elements;
+};
+
+inline bool aligned(const void* p, i64 a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int ilog2ceil(long long x) {
+  int l = 0;
+  while ((1LL << l) < x) ++l;
+  return l;
+}
+
+template <int ES>
+constexpr int tileI() {
+  return ES == 16 ? 32 : 64;
+}
+
+Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelTuning* tuning) {
+  Move3D m = in;
+  normalizeMove(m);
+  Classified c{};
+  c.elements = m.elements();
+  c.dm.src = static_cast<const char*>(bufs[m.src_buf]) + m.src_off * es;
+  c.dm.dst = static_cast<char*>(bufs[m.dst_buf]) + m.dst_off * es;
+  const bool force_generic = tuning && tuning->force_class == MOVE_GENERIC;
+
+  if (!force_generic && m.ss[0] <= 1 && m.ds[0] <= 1) {
+    // rows contiguous on both sides (also the all-extents-1 case).  Widest vector the addresses allow.
+    int vb = 16;
+    for (; vb > es; vb >>= 1) {
+      bool ok = aligned(c.dm.src, vb) && aligned(c.dm.dst, vb) && (m.extent[0] * es) % vb == 0;
+      for (int i = 1; i < 3 && ok; ++i) ok = (m.ss[i] * es) % vb == 0 && (m.ds[i] * es) % vb == 0;
+      if (ok) break;
+    }
+    if (vb < es) vb = es;
+    c.cls = MOVE_ROWS_VEC;
+    c.variant = vb;
+    const i64 scale = vb / es;  // elements per vector (vb >= es always holds here)
+    c.dm.e[0] = m.extent[0] / scale;
+    c.dm.e[1] = m.extent[1];
+    c.dm.e[2] = m.extent[2];
+    for (int i = 1; i < 3; ++i) {
+      c.dm.ss[i] = m.ss[i] / scale;
+      c.dm.ds[i] = m.ds[i] / scale;
+    }
+    c.p0 = std::min(8, ilog2ceil(c.dm.e[0]));
+    const long long lpr = 1LL << c.p0, rows_per_block = (long long)(kThreads >> c.p0) * kRowsUnroll;
+    c.t0 = (unsigned int)((c.dm.e[0] + lpr - 1) / lpr);
+    c.t1 = (unsigned int)((c.dm.e[1] + rows_per_block - 1) / rows_per_block);
+    c.blocks = (unsigned long long)c.t0 * c.t1 * (unsigned long long)c.dm.e[2];
+    return c;
+  }
+
+  int t = -1;
+  if (!force_generic && m.ss[0] == 1) {
+    if (m.ds[1] == 1) t = 1;
+    if (m.ds[2] == 1) t = 2;
+  }
+  if (t > 0 && m.extent[0] >= 4 && m.extent[t] >= 4) {
+    const int k = 3 - t;
+    c.cls = MOVE_TRANSPOSE;
+    c.dm.e[0] = m.extent[0];
+    c.dm.e[1] = m.extent[t];
+    c.dm.e[2] = m.extent[k];
+    c.dm.ss[0] = 1;
+    c.dm.ss[1] = m.ss[t];
+    c.dm.ss[2] = m.ss[k];
+    c.dm.ds[0] = m.ds[0];
+    c.dm.ds[1] = 1;
+    c.dm.ds[2] = m.ds[k];
+    int vw = 16 / es;
+    if (vw > 1) {
+      const i64 vb = 16;
+      bool ok = aligned(c.dm.src, vb) && aligned(c.dm.dst, vb) && c.dm.e[0] % vw == 0 && c.dm.e[1] % vw == 0 &&
+                c.dm.ss[1] % vw == 0 && c.dm.ss[2] % vw == 0 && c.dm.ds[0] % vw == 0 && c.dm.ds[2] % vw == 0;
+      if (!ok) vw = 1;
+    }
+    c.variant = vw;
+    const int ti = (es == 16) ? 32 : 64, tj = ti;
+    c.t0 = (unsigned int)((c.dm.e[0] + ti - 1) / ti);
+    c.t1 = (unsigned int)((c.dm.e[1] + tj - 1) / tj);
+    c.blocks = (unsigned long long)c.t0 * c.t1 * (unsigned long long)c.dm.e[2];
+    return c;
+  }
+
+  c.cls = MOVE_GENERIC;
+  c.variant = es;
+  for (int i = 0; i < 3; ++i) {
+    c.dm.e[i] = m.extent[i];
+    c.dm.ss[i] = m.ss[i];
+    c.dm.ds[i] = m.ds[i];
+  }
+  c.p0 = 0;
+  for (int i = 0; i < 3; ++i)
+    if (m.ds[i] == 1 && m.extent[i] > 1) c.p0 = i;
+  const unsigned long long want = ((unsigned long long)c.elements + kThreads - 1) / kThreads;
+  c.blocks = std::min<unsigned long long>(std::max<unsigned long long>(want, 1), 8192);
+  return c;
+}
+
+void launchBatch(MoveClass cls, int variant, int es, const Batch& b, unsigned int blocks, hipStream_t stream) {
+  const dim3 grid(blocks), block(kThreads);
+  switch (cls) {
+    case MOVE_ROWS_VEC:
+      if (variant == 16) rows_kernel<16><<<grid, block, 0, stream>>>(b);
+      else if (variant == 8) rows_kernel<8><<<grid, block, 0, stream>>>(b);
+      else rows_kernel<4><<<grid, block, 0, stream>>>(b);
+      break;
+    case MOVE_TRANSPOSE:
+      if (es == 4) {
+        if (variant == 4) transpose_kernel<4, 4, 64, 64><<<grid, block, 0, stream>>>(b);
+        else transpose_kernel<4, 1, 64, 64><<<grid, block, 0, stream>>>(b);
+      } else if (es == 8) {
+        if (variant == 2) transpose_kernel<8, 2, 64, 64><<<grid, block, 0, stream>>>(b);
+        else transpose_kernel<8, 1, 64, 64><<<grid, block, 0, stream>>>(b);
+      } else {
+        transpose_kernel<16, 1, 32, 32><<<grid, block, 0, stream>>>(b);
+      }
+      break;
+    default:
+      if (es == 4) generic_kernel<4><<<grid, block, 0, stream>>>(b);
+      else if (es == 8) generic_kernel<8><<<grid, block, 0, stream>>>(b);
+      else generic_kernel<16><<<grid, block, 0, stream>>>(b);
+      break;
+  }
+  CD_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStream_t stream,
+                 const KernelTuning* tuning, KernelStats* stats) {
+  if (es != 4 && es != 8 && es != 16) CD_INTERNAL_ERROR("unsupported element size");
+  std::vector<Classified> cs;
+  cs.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    if (moves[i].elements() == 0) continue;
+    cs.push_back(classify(moves[i], bufs, es, tuning));
+  }
+  // moves of one phase are independent, so they may be regrouped by kernel flavour
+  std::vector<bool> done(cs.size(), false);
+  for (size_t i = 0; i < cs.size(); ++i) {
+    if (done[i]) continue;
+    Batch b{};
+    unsigned long long blocks = 0;
+    for (size_t j = i; j < cs.size() && b.n < kMaxBatch; ++j) {
+      if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant) continue;
+      if (blocks + cs[j].blocks > 0x7fffffffULL) {
+        if (b.n == 0) CD_NOT_SUPPORTED("single block move too large for one launch");
+        break;
+      }
+      b.first_block[b.n] = (unsigned int)blocks;
+      b.m[b.n] = cs[j].dm;
+      b.p0[b.n] = cs[j].p0;
+      b.t0[b.n] = cs[j].t0;
+      b.t1[b.n] = cs[j].t1;
+      blocks += cs[j].blocks;
+      if (stats) stats->elements[cs[j].cls] += cs[j].elements;
+      ++b.n;
+      done[j] = true;
+    }
+    b.first_block[b.n] = (unsigned int)blocks;
+    launchBatch(cs[i].cls, cs[i].variant, es, b, (unsigned int)blocks, stream);
+    if (stats) stats->launches[cs[i].cls] += 1;
+  }
+}
+
+}  // namespace cudecomp

@@ -1,0 +1,90 @@
+// plan.h -- transposes and halo updates as DATA: a short list of strided block moves plus the
+// exchange counts, built once per (operation, halos, padding, in-place, transport traits) and cached
+// on the grid descriptor.  The executors (transpose.cc, halo.cc) only bind pointers and launch.
+//
+// Everything a transpose does locally is a Move3D:
+//     dst[dst_off + k0*ds[0] + k1*ds[1] + k2*ds[2]] = src[src_off + k0*ss[0] + k1*ss[1] + k2*ss[2]]
+// for 0 <= k_i < extent[i], all in ELEMENTS.  A pack, an unpack, a halo face copy and a full 3-D
+// permutation are the same object; the kernel layer (kernels.hip) picks the access pattern.
+//
+// What the plan must reproduce (bit-exact interior of the output pencil) is defined by
+// NVIDIA/cuDecomp's cudecompTranspose_ / cudecompUpdateHalos_ (reference
+// include/internal/transpose.h:196-905, include/internal/halo.h:41-315).  The plan is derived from
+// the decomposition itself rather than transcribed from that code: see DESIGN.md "Plan".
+#pragma once
+#include <vector>
+
+#include "decomp.h"
+
+namespace cudecomp {
+
+enum BufId : uint8_t { BUF_IN = 0, BUF_OUT = 1, BUF_WORK = 2 };
+
+struct Move3D {
+  BufId src_buf = BUF_IN, dst_buf = BUF_OUT;
+  i64 src_off = 0, dst_off = 0;
+  i64 extent[3] = {1, 1, 1};
+  i64 ss[3] = {0, 0, 0};
+  i64 ds[3] = {0, 0, 0};
+  int peer = -1;  // communicator rank this move feeds / drains (-1: not tied to one peer)
+
+  i64 elements() const { return extent[0] * extent[1] * extent[2]; }
+};
+
+// Traits of the transport that change the plan (not the result).
+struct TransportTraits {
+  bool pipelined = false;        // per-peer overlap of pack / exchange / unpack
+  bool symmetric_recv = false;   // one-sided peer writes: receive area must sit at the same workspace offset on
+                                 // every rank and inside the workspace (never in the user's output buffer)
+};
+
+struct TransposePlan {
+  // identification
+  int ax_a = 0, ax_b = 0, ax_c = 0;
+  CommAxis comm_axis = COMM_COL;
+  int nranks = 1, comm_rank = 0;  // size of / my rank in the exchanging communicator
+  bool noop = false;              // nothing to do at all (single rank, in place, identical layout)
+
+  std::vector<Move3D> pack;    // before the exchange (schedule order: peers first, self last)
+  std::vector<Move3D> unpack;  // after the exchange (self first)
+
+  // exchange: chunk for member d starts at send_off[d] of (send_buf + send_base); the chunk from
+  // member s lands at recv_off[s] of (recv_buf + recv_base); all in elements
+  bool exchange = false;
+  BufId send_buf = BUF_WORK, recv_buf = BUF_WORK;
+  i64 send_base = 0, recv_base = 0;
+  std::vector<i64> send_cnt, send_off, recv_cnt, recv_off;
+  std::vector<i64> remote_recv_off;  // where MY chunk lands in member d's receive area (one-sided transports)
+  std::vector<int> schedule_dst, schedule_src;  // pairwise peer order, entry 0 = self
+
+  i64 pencil_elements_a = 0;  // interior elements moved (for bandwidth accounting)
+};
+
+enum TransposeOp { OP_X_TO_Y = 0, OP_Y_TO_Z = 1, OP_Z_TO_Y = 2, OP_Y_TO_X = 3 };
+
+TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, const int32_t* in_halo,
+                                 const int32_t* out_halo, const int32_t* in_pad, const int32_t* out_pad, bool inplace,
+                                 const TransportTraits& traits, int npergroup);
+
+struct HaloPlan {
+  int axis = 0, dim = 0;
+  enum Kind { NONE, SELF_PERIODIC, PACKED, DIRECT } kind = NONE;
+  CommAxis comm_axis = COMM_COL;
+  int neighbor[2] = {-1, -1};  // global ranks of the -1 / +1 neighbours (-1: none)
+  std::vector<Move3D> pre;     // SELF_PERIODIC: the two wrap copies; PACKED: face -> workspace
+  std::vector<Move3D> post;    // PACKED: workspace -> halo
+  // exchange in elements.  Face i (0 = low side, 1 = high side) is SENT to neighbour i and halo slot i is
+  // FILLED by neighbour i.  Offsets are relative to the pencil (DIRECT) or the workspace (PACKED).
+  i64 face_elements = 0;
+  BufId xbuf = BUF_WORK;
+  i64 send_off[2] = {0, 0}, recv_off[2] = {0, 0};
+};
+
+HaloPlan buildHaloPlan(const GridShape& g, int rank, int axis, int dim, const int32_t* halo, const bool* periods,
+                       const int32_t* pad, bool force_packed);
+
+// canonical form used by the kernel layer: unit-extent dims dropped, mergeable dims fused, dims
+// ordered by source stride.  Returns the number of remaining dims (0..3).
+int normalizeMove(Move3D& m);
+
+}  // namespace cudecomp

@@ -1,0 +1,356 @@
+// transport.cc -- see transport.h
+#include "transport.h"
+
+#include <algorithm>
+#include <cstring>
+
+#include <rccl/rccl.h>
+#include <unistd.h>
+
+#include "errors.h"
+
+namespace cudecomp {
+
+// ================================================================================================
+// world bootstrap
+// ================================================================================================
+#ifndef CUDECOMP_WITH_MPI
+std::unique_ptr<Bootstrap> makeWorldBootstrap(MPI_Comm comm, int instance) {
+  // Built without MPI: the communicator is only a token for "all ranks the launcher started".
+  if (comm == MPI_COMM_NULL) CD_INVALID_USAGE("null communicator");
+  const LaunchEnv env = detectLaunchEnv();
+  if (env.size == 1) return makeLocalBootstrap();
+  return makeTcpBootstrap(env, instance);
+}
+MPI_Comm commFromFortran(MPI_Fint f) { return (MPI_Comm)f; }
+#endif
+
+// ================================================================================================
+// RCCL
+// ================================================================================================
+class RcclContext {
+ public:
+  explicit RcclContext(cudecompHandle_t h) {
+    ncclUniqueId id;
+    std::memset(&id, 0, sizeof(id));
+    if (h->rank == 0) CD_CHECK_RCCL(ncclGetUniqueId(&id));
+    h->boot->bcast(&id, sizeof(id), 0);
+    CD_CHECK_RCCL(ncclCommInitRank(&comm_, h->nranks, id, h->rank));
+  }
+  ~RcclContext() {
+    if (comm_) ncclCommDestroy(comm_);
+  }
+  ncclComm_t comm() const { return comm_; }
+
+ private:
+  ncclComm_t comm_ = nullptr;
+};
+
+// ================================================================================================
+// PEER: IPC-mapped buffers + one-sided xGMI copies
+// ================================================================================================
+class PeerContext {
+ public:
+  struct Region {
+    char* base = nullptr;
+    size_t bytes = 0;
+    std::vector<char*> peer_base;  // by global rank; [my rank] = base
+    bool from_library = false;     // allocated by cudecompMalloc
+  };
+
+  explicit PeerContext(cudecompHandle_t h) : h_(h) {}
+
+  ~PeerContext() {
+    for (auto& kv : regions_) closePeers(kv.second);
+    for (hipStream_t s : copy_streams_) (void)hipStreamDestroy(s);
+  }
+
+  Region* find(const void* ptr) {
+    const char* p = static_cast<const char*>(ptr);
+    auto it = regions_.upper_bound(const_cast<char*>(p));
+    if (it == regions_.begin()) return nullptr;
+    --it;
+    Region& r = it->second;
+    return (p >= r.base && p < r.base + r.bytes) ? &r : nullptr;
+  }
+
+  // collective over the handle's communicator
+  Region* registerRegion(void* base, size_t bytes, bool from_library) {
+    struct Wire {
+      hipIpcMemHandle_t handle;
+      unsigned long long bytes;
+      int pid;
+    };
+    Wire mine{};
+    CD_CHECK_HIP(hipIpcGetMemHandle(&mine.handle, base));
+    mine.bytes = bytes;
+    mine.pid = (int)::getpid();
+    std::vector<Wire> all(h_->nranks);
+    h_->boot->allgather(&mine, all.data(), sizeof(Wire));
+    Region r;
+    r.base = static_cast<char*>(base);
+    r.bytes = bytes;
+    r.from_library = from_library;
+    r.peer_base.assign(h_->nranks, nullptr);
+    for (int p = 0; p < h_->nranks; ++p) {
+      if (p == h_->rank) {
+        r.peer_base[p] = r.base;
+        continue;
+      }
+      if (h_->hostnames[p] != h_->hostnames[h_->rank]) continue;  // no xGMI path: not mappable
+      void* mapped = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&mapped, all[p].handle, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        CD_PEER_ERROR(std::string("hipIpcOpenMemHandle failed: ") + hipGetErrorString(e) +
+                      " (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)");
+      }
+      r.peer_base[p] = static_cast<char*>(mapped);
+    }
+    h_->boot->barrier();
+    auto ins = regions_.emplace(r.base, std::move(r));
+    return &ins.first->second;
+  }
+
+  // collective
+  void unregisterRegion(void* base) {
+    auto it = regions_.find(static_cast<char*>(base));
+    if (it == regions_.end()) return;
+    h_->boot->barrier();  // nobody is still writing into a mapping that is about to disappear
+    closePeers(it->second);
+    regions_.erase(it);
+    h_->boot->barrier();
+  }
+
+  // pointer through which `global_rank`'s copy of my buffer location `local` can be written; registers
+  // the enclosing allocation on first sight (collective: every rank reaches this in the same call)
+  char* translate(const void* local, int global_rank) {
+    Region* r = find(local);
+    if (!r) {
+      void* base = nullptr;
+      size_t bytes = 0;
+      CD_CHECK_HIP(hipMemGetAddressRange(&base, &bytes, const_cast<void*>(local)));
+      r = registerRegion(base, bytes, false);
+    }
+    char* pb = r->peer_base[global_rank];
+    if (!pb) CD_PEER_ERROR("peer buffer is not reachable over xGMI/IPC (rank on another host?)");
+    return pb + (static_cast<const char*>(local) - r->base);
+  }
+
+  bool anyUnregistered(const void* local) { return find(local) == nullptr; }
+
+  hipStream_t copyStream(int i) {
+    while ((int)copy_streams_.size() <= i) {
+      hipStream_t s;
+      CD_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+      copy_streams_.push_back(s);
+    }
+    return copy_streams_[i];
+  }
+
+ private:
+  void closePeers(Region& r) {
+    for (int p = 0; p < (int)r.peer_base.size(); ++p)
+      if (p != h_->rank && r.peer_base[p]) (void)hipIpcCloseMemHandle(r.peer_base[p]);
+  }
+
+  cudecompHandle_t h_;
+  std::map<char*, Region> regions_;
+  std::vector<hipStream_t> copy_streams_;
+};
+
+void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
+  if (h->nranks == 1) return;  // every communicator has one member: nothing ever travels
+  if (need_rccl && !h->rccl) {
+    ensureDevice(h);
+    h->rccl = std::make_shared<RcclContext>(h);
+  }
+  if (need_peer && !h->peer) h->peer = std::make_shared<PeerContext>(h);  // touches the device on first use only
+}
+
+void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes) {
+  const bool peer_backend = !transposeBackendIsRccl(gd->config.transpose_comm_backend) ||
+                            !haloBackendIsRccl(gd->config.halo_comm_backend);
+  void* ptr = nullptr;
+  if (h->nranks > 1 && peer_backend) {
+    // one-sided writes address the peer's workspace by offset: make it the same size everywhere
+    bytes = (size_t)h->boot->allreduceMaxI64((int64_t)bytes);
+    prepareTransports(h, false, true);
+    CD_CHECK_HIP(hipMalloc(&ptr, bytes));
+    try {
+      h->peer->registerRegion(ptr, bytes, true);
+    } catch (...) {
+      (void)hipFree(ptr);
+      throw;
+    }
+    return ptr;
+  }
+  CD_CHECK_HIP(hipMalloc(&ptr, bytes));
+  return ptr;
+}
+
+void workspaceFree(cudecompHandle_t h, cudecompGridDesc_t, void* ptr) {
+  if (h->peer && h->peer->find(ptr) && h->peer->find(ptr)->base == ptr) h->peer->unregisterRegion(ptr);
+  CD_CHECK_HIP(hipFree(ptr));
+}
+
+// ================================================================================================
+// all-to-all
+// ================================================================================================
+namespace {
+
+bool usesRccl(cudecompTransposeCommBackend_t b) { return transposeBackendIsRccl(b); }
+
+// uniform chunks laid out back to back, exchanged by the whole RCCL communicator in rank order
+bool nativeAlltoallEligible(cudecompHandle_t h, const cudecompCommInfo& ci, const TransposePlan& p) {
+  if (ci.nranks != h->nranks) return false;
+  for (int i = 0; i < ci.nranks; ++i) {
+    if (ci.global_ranks[i] != i) return false;
+    if (p.send_cnt[i] != p.send_cnt[0] || p.recv_cnt[i] != p.send_cnt[0]) return false;
+    if (p.send_off[i] != i * p.send_cnt[0] || p.recv_off[i] != i * p.send_cnt[0]) return false;
+  }
+  return true;
+}
+
+void rcclAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& p, const ExchangeBuffers& b, int es,
+                  hipStream_t stream) {
+  if (!h->rccl) CD_INTERNAL_ERROR("RCCL communicator was not created for this grid descriptor");
+  ncclComm_t comm = h->rccl->comm();
+  if (nativeAlltoallEligible(h, ci, p)) {
+    CD_CHECK_RCCL(ncclAllToAll(b.send, b.recv, (size_t)p.send_cnt[0] * es, ncclInt8, comm, stream));
+    return;
+  }
+  CD_CHECK_RCCL(ncclGroupStart());
+  for (int i = 0; i < ci.nranks; ++i) {
+    const int peer = ci.global_ranks[i];
+    if (p.send_cnt[i]) CD_CHECK_RCCL(ncclSend(b.send + p.send_off[i] * es, (size_t)p.send_cnt[i] * es, ncclInt8, peer, comm, stream));
+    if (p.recv_cnt[i]) CD_CHECK_RCCL(ncclRecv(b.recv + p.recv_off[i] * es, (size_t)p.recv_cnt[i] * es, ncclInt8, peer, comm, stream));
+  }
+  CD_CHECK_RCCL(ncclGroupEnd());
+}
+
+// One-sided exchange.  Host-ordered: (1) my chunks are packed (stream sync), (2) everybody's are and
+// everybody's receive area is free (barrier), (3) P-1 concurrent xGMI copies, one stream per peer so that
+// every link / SDMA queue is busy, (4) all copies landed everywhere (sync + barrier).
+void peerAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& p, const ExchangeBuffers& b, int es,
+                  hipStream_t stream) {
+  if (!h->peer) CD_INTERNAL_ERROR("peer transport was not created for this grid descriptor");
+  PeerContext& pc = *h->peer;
+  CD_CHECK_HIP(hipStreamSynchronize(stream));
+  // translate first: registering a foreign receive buffer is itself collective
+  std::vector<char*> remote(ci.nranks, nullptr);
+  for (int j = 0; j < ci.nranks; ++j) {
+    const int d = p.schedule_dst[j];
+    remote[d] = pc.translate(b.recv, ci.global_ranks[d]) + p.remote_recv_off[d] * es;
+  }
+  ci.boot->barrier();
+  for (int j = 0; j < ci.nranks; ++j) {
+    const int d = p.schedule_dst[j];
+    if (p.send_cnt[d] == 0) continue;
+    CD_CHECK_HIP(hipMemcpyAsync(remote[d], b.send + p.send_off[d] * es, (size_t)p.send_cnt[d] * es,
+                                hipMemcpyDeviceToDevice, pc.copyStream(j)));
+  }
+  for (int j = 0; j < ci.nranks; ++j) CD_CHECK_HIP(hipStreamSynchronize(pc.copyStream(j)));
+  ci.boot->barrier();
+}
+
+}  // namespace
+
+void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t, cudecompCommInfo& ci, const TransposePlan& plan,
+                      const ExchangeBuffers& b, int es, cudecompTransposeCommBackend_t backend, hipStream_t stream) {
+  if (usesRccl(backend)) rcclAlltoall(h, ci, plan, b, es, stream);
+  else peerAlltoall(h, ci, plan, b, es, stream);
+}
+
+void alltoallExchangePeers(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
+                           const ExchangeBuffers& b, int es, cudecompTransposeCommBackend_t backend,
+                           const std::vector<int>& src_members, const std::vector<int>& dst_members,
+                           hipStream_t stream) {
+  if (src_members.empty()) return;
+  const int me = ci.rank;
+  if (!usesRccl(backend)) {
+    // The one-sided transport synchronises on the host, so there is nothing to gain from splitting the
+    // exchange by peer: run all of it when the schedule reaches the self step, which comes first.
+    if (src_members[0] == me) peerAlltoall(h, ci, plan, b, es, stream);
+    return;
+  }
+  if (!h->rccl) CD_INTERNAL_ERROR("RCCL communicator was not created for this grid descriptor");
+  if (h->streams.empty()) {
+    int lo = 0, hi = 0;
+    CD_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t s;
+    CD_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+    h->streams.push_back(s);
+  }
+  hipStream_t side = h->streams[0];
+  ncclComm_t comm = h->rccl->comm();
+  bool grouped = false;
+  for (size_t i = 0; i < src_members.size(); ++i) {
+    const int s = src_members[i], d = dst_members[i];
+    if (s == me) {
+      CD_CHECK_HIP(hipMemcpyAsync(b.recv + plan.recv_off[me] * es, b.send + plan.send_off[me] * es,
+                                  (size_t)plan.send_cnt[me] * es, hipMemcpyDeviceToDevice, stream));
+      continue;
+    }
+    CD_CHECK_HIP(hipStreamWaitEvent(side, gd->events[d], 0));  // chunk for d is packed
+    if (!grouped) {
+      CD_CHECK_RCCL(ncclGroupStart());
+      grouped = true;
+    }
+    if (plan.send_cnt[d])
+      CD_CHECK_RCCL(ncclSend(b.send + plan.send_off[d] * es, (size_t)plan.send_cnt[d] * es, ncclInt8,
+                             ci.global_ranks[d], comm, side));
+    if (plan.recv_cnt[s])
+      CD_CHECK_RCCL(ncclRecv(b.recv + plan.recv_off[s] * es, (size_t)plan.recv_cnt[s] * es, ncclInt8,
+                             ci.global_ranks[s], comm, side));
+  }
+  if (grouped) CD_CHECK_RCCL(ncclGroupEnd());
+  for (size_t i = 0; i < src_members.size(); ++i) {
+    if (src_members[i] == me) continue;
+    const int d = dst_members[i];
+    CD_CHECK_HIP(hipEventRecord(gd->events[d], side));
+    CD_CHECK_HIP(hipStreamWaitEvent(stream, gd->events[d], 0));  // chunk has arrived: unpack may start
+  }
+}
+
+// ================================================================================================
+// halo exchange
+// ================================================================================================
+void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x, cudecompHaloCommBackend_t backend,
+                  hipStream_t stream) {
+  if (haloBackendIsRccl(backend)) {
+    if (!h->rccl) CD_INTERNAL_ERROR("RCCL communicator was not created for this grid descriptor");
+    ncclComm_t comm = h->rccl->comm();
+    // Between one pair of ranks RCCL matches sends and receives in issue order.  With two ranks along a
+    // periodic dimension both neighbours are the same peer, so the HIGH face must be sent first: it pairs
+    // with the peer's first receive, its LOW halo slot.
+    CD_CHECK_RCCL(ncclGroupStart());
+    for (int i = 0; i < 2; ++i) {
+      const int s = 1 - i;  // face sent in this step
+      if (x.neighbor[s] != -1)
+        CD_CHECK_RCCL(ncclSend(x.send + x.send_off[s], (size_t)x.bytes, ncclInt8, x.neighbor[s], comm, stream));
+      if (x.neighbor[i] != -1)
+        CD_CHECK_RCCL(ncclRecv(x.recv + x.recv_off[i], (size_t)x.bytes, ncclInt8, x.neighbor[i], comm, stream));
+    }
+    CD_CHECK_RCCL(ncclGroupEnd());
+    return;
+  }
+  if (!h->peer) CD_INTERNAL_ERROR("peer transport was not created for this grid descriptor");
+  PeerContext& pc = *h->peer;
+  cudecompCommInfo& ci = gd->comm(x.comm_axis);
+  CD_CHECK_HIP(hipStreamSynchronize(stream));
+  char* remote[2] = {nullptr, nullptr};
+  // registration of a foreign buffer is collective over the world: do it unconditionally and first
+  if (pc.anyUnregistered(x.recv)) (void)pc.translate(x.recv, h->rank);
+  for (int i = 0; i < 2; ++i)
+    if (x.neighbor[i] != -1) remote[i] = pc.translate(x.recv, x.neighbor[i]) + x.remote_off[i];
+  ci.boot->barrier();
+  for (int i = 0; i < 2; ++i)
+    if (x.neighbor[i] != -1)
+      CD_CHECK_HIP(hipMemcpyAsync(remote[i], x.send + x.send_off[i], (size_t)x.bytes, hipMemcpyDeviceToDevice,
+                                  pc.copyStream(i)));
+  for (int i = 0; i < 2; ++i) CD_CHECK_HIP(hipStreamSynchronize(pc.copyStream(i)));
+  ci.boot->barrier();
+}
+
+}  // namespace cudecomp

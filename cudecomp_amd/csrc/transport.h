@@ -1,0 +1,65 @@
+// transport.h -- the data plane between GPUs.
+//
+// Two transports carry array data on an MI355X node (8 GPUs, full xGMI mesh, one link per GPU pair):
+//
+//   RCCL  (NCCL / NCCL_PL enums, HALO_COMM_NCCL): grouped ncclSend/ncclRecv (or ncclAllToAll when the
+//         chunks are uniform and the communicator is the whole world) on the caller's stream;
+//         fully stream-asynchronous.  Replaces reference include/internal/comm_routines.h:296-322, 533-584,
+//         686-707.
+//   PEER  (NVSHMEM* enums; also the MPI_* enums when the library is built without MPI): one-sided copies
+//         over xGMI into the receiver's IPC-mapped buffer.  Every pair of GPUs owns a dedicated link, so
+//         the P-1 copies of an all-to-all are issued at once, each on its own stream/SDMA queue.
+//         Replaces the reference's NVSHMEM put path (comm_routines.h:122-258) and stands in for
+//         CUDA-aware MPI (comm_routines.h:325-413).  Needs the written buffer to be visible to the peer:
+//         buffers from cudecompMalloc are mapped once at allocation; other buffers are mapped on first use.
+//
+// A build with MPI=1 adds the ROCm-aware-MPI implementation of the MPI_* enums (transport_mpi.cc).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "internal.h"
+
+namespace cudecomp {
+
+std::unique_ptr<Bootstrap> makeWorldBootstrap(MPI_Comm comm, int instance);
+MPI_Comm commFromFortran(MPI_Fint f);
+
+// collective: create the RCCL communicator / the peer registry if they will be needed
+void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer);
+
+void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes);  // collective
+void workspaceFree(cudecompHandle_t h, cudecompGridDesc_t gd, void* ptr);       // collective
+
+struct ExchangeBuffers {
+  char* send;  // base of the send area (device pointer)
+  char* recv;  // base of the receive area (device pointer)
+};
+
+// All-to-all of the plan's chunks among the members of `ci`.  `stream` carries the pack kernels before and
+// the unpack kernels after; on return the exchange is ordered on `stream` (possibly after blocking the host,
+// as the reference's MPI backends do).
+void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
+                      const ExchangeBuffers& b, int es, cudecompTransposeCommBackend_t backend, hipStream_t stream);
+
+// Per-peer variant used by the pipelined backends: exchange with the given members only.  Waits for
+// pack_done[dst] before sending to dst and makes `stream` wait for the arrival of each chunk.
+void alltoallExchangePeers(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
+                           const ExchangeBuffers& b, int es, cudecompTransposeCommBackend_t backend,
+                           const std::vector<int>& src_members, const std::vector<int>& dst_members,
+                           hipStream_t stream);
+
+// Halo exchange: face i (at send + send_off[i]) goes to neighbour i, slot i (recv + recv_off[i]) is filled by
+// neighbour i; neighbour -1 = nothing on that side.  remote_off[i] = offset of MY face inside neighbour i's
+// receive buffer (used by the one-sided transport).
+struct HaloExchange {
+  char* send;
+  char* recv;
+  i64 send_off[2], recv_off[2], remote_off[2];  // bytes
+  i64 bytes;
+  int neighbor[2];  // global ranks
+  CommAxis comm_axis;  // communicator the neighbours belong to
+};
+void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x,
+                  cudecompHaloCommBackend_t backend, hipStream_t stream);
+
+}  // namespace cudecomp

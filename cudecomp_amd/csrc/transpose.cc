@@ -1,0 +1,150 @@
+// transpose.cc -- executes transpose and halo plans: bind pointers, launch the move kernels, run the
+// exchange.  The algorithmic content lives in plan.cc (what moves where) and kernels.hip (how).
+#include "errors.h"
+#include "internal.h"
+#include "transport.h"
+
+namespace cudecomp {
+
+namespace {
+
+bool usesPeerTransport(cudecompTransposeCommBackend_t b) {
+#ifdef CUDECOMP_WITH_MPI
+  return transposeBackendIsPeer(b);
+#else
+  return !transposeBackendIsRccl(b);
+#endif
+}
+bool usesPeerTransport(cudecompHaloCommBackend_t b) {
+#ifdef CUDECOMP_WITH_MPI
+  return haloBackendIsPeer(b);
+#else
+  return !haloBackendIsRccl(b);
+#endif
+}
+
+std::array<int32_t, 3> arr3(const int32_t* p) {
+  return p ? std::array<int32_t, 3>{p[0], p[1], p[2]} : std::array<int32_t, 3>{0, 0, 0};
+}
+
+}  // namespace
+
+void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, void* input, void* output, void* work,
+                  cudecompDataType_t dtype, const int32_t* in_halo, const int32_t* out_halo, const int32_t* in_pad,
+                  const int32_t* out_pad, hipStream_t stream) {
+  const int es = elementSize(dtype);
+  const bool inplace = (input == output);
+  const auto backend = gd->config.transpose_comm_backend;
+  TransportTraits traits;
+  traits.pipelined = transposeBackendIsPipelined(backend);
+  traits.symmetric_recv = usesPeerTransport(backend);
+
+  std::array<int32_t, 12> hp;
+  {
+    const auto a = arr3(in_halo), b = arr3(out_halo), c = arr3(in_pad), d = arr3(out_pad);
+    for (int i = 0; i < 3; ++i) {
+      hp[i] = a[i];
+      hp[3 + i] = b[i];
+      hp[6 + i] = c[i];
+      hp[9 + i] = d[i];
+    }
+  }
+  const cudecompGridDesc::TransposeKey key{(int)op, hp, inplace, traits.pipelined, traits.symmetric_recv};
+  auto it = gd->transpose_plans.find(key);
+  if (it == gd->transpose_plans.end()) {
+    const auto& ci = gd->comm((op == OP_X_TO_Y || op == OP_Y_TO_X) ? COMM_COL : COMM_ROW);
+    TransposePlan p = buildTransposePlan(gd->shape, h->rank, op, &hp[0], &hp[3], &hp[6], &hp[9], inplace, traits,
+                                         ci.npergroup);
+    it = gd->transpose_plans.emplace(key, std::move(p)).first;
+  }
+  const TransposePlan& plan = it->second;
+  if (plan.noop) return;
+
+  ensureDevice(h);
+  void* bufs[3] = {input, output, work};
+
+  if (!plan.exchange) {
+    launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
+    launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
+    return;
+  }
+
+  cudecompCommInfo& ci = gd->comm(plan.comm_axis);
+  ExchangeBuffers xb;
+  xb.send = static_cast<char*>(bufs[plan.send_buf]) + plan.send_base * es;
+  xb.recv = static_cast<char*>(bufs[plan.recv_buf]) + plan.recv_base * es;
+
+  if (!traits.pipelined) {
+    launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
+    alltoallExchange(h, gd, ci, plan, xb, es, backend, stream);
+    launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
+    return;
+  }
+
+  // Per-peer pipeline: pack chunk by chunk (an event per destination), then walk the pairwise schedule:
+  // exchange with one peer on the side stream while the previous peer's chunk is being unpacked.
+  const int P = plan.nranks;
+  if ((int)gd->events.size() < P) {
+    const size_t old = gd->events.size();
+    gd->events.resize(P);
+    for (size_t i = old; i < gd->events.size(); ++i)
+      CD_CHECK_HIP(hipEventCreateWithFlags(&gd->events[i], hipEventDisableTiming));
+  }
+  if (!plan.pack.empty()) {
+    for (const Move3D& m : plan.pack) {
+      launchMoves(&m, 1, bufs, es, stream, &h->tuning);
+      CD_CHECK_HIP(hipEventRecord(gd->events[m.peer], stream));
+    }
+  } else {
+    for (int d = 0; d < P; ++d) CD_CHECK_HIP(hipEventRecord(gd->events[d], stream));
+  }
+  for (int j = 0; j < P; ++j) {
+    const int src = (j == 0) ? plan.comm_rank : plan.schedule_src[j];
+    const int dst = (j == 0) ? plan.comm_rank : plan.schedule_dst[j];
+    alltoallExchangePeers(h, gd, ci, plan, xb, es, backend, {src}, {dst}, stream);
+    for (const Move3D& m : plan.unpack)
+      if (m.peer == src) launchMoves(&m, 1, bufs, es, stream, &h->tuning);
+  }
+}
+
+void runHalo(cudecompHandle_t h, cudecompGridDesc_t gd, int axis, void* input, void* work, cudecompDataType_t dtype,
+             const int32_t* halo, const bool* periods, int dim, const int32_t* pad, hipStream_t stream) {
+  const int es = elementSize(dtype);
+  const auto backend = gd->config.halo_comm_backend;
+  const bool force_packed = usesPeerTransport(backend);
+
+  const auto hh = arr3(halo), pp = arr3(pad);
+  std::array<bool, 3> per{false, false, false};
+  if (periods)
+    for (int i = 0; i < 3; ++i) per[i] = periods[i];
+  const cudecompGridDesc::HaloKey key{axis, dim, {hh[0], hh[1], hh[2], pp[0], pp[1], pp[2]}, per, force_packed};
+  auto it = gd->halo_plans.find(key);
+  if (it == gd->halo_plans.end()) {
+    HaloPlan p = buildHaloPlan(gd->shape, h->rank, axis, dim, hh.data(), per.data(), pp.data(), force_packed);
+    it = gd->halo_plans.emplace(key, std::move(p)).first;
+  }
+  const HaloPlan& plan = it->second;
+  if (plan.kind == HaloPlan::NONE) return;
+
+  ensureDevice(h);
+  void* bufs[3] = {input, input, work};
+  if (plan.kind == HaloPlan::SELF_PERIODIC) {
+    launchMoves(plan.pre.data(), (int)plan.pre.size(), bufs, es, stream, &h->tuning);
+    return;
+  }
+  HaloExchange x;
+  x.send = x.recv = static_cast<char*>(bufs[plan.xbuf]);
+  for (int i = 0; i < 2; ++i) {
+    x.send_off[i] = plan.send_off[i] * es;
+    x.recv_off[i] = plan.recv_off[i] * es;
+    x.remote_off[i] = plan.recv_off[1 - i] * es;  // my low face fills the low neighbour's HIGH halo slot
+    x.neighbor[i] = plan.neighbor[i];
+  }
+  x.bytes = plan.face_elements * es;
+  x.comm_axis = plan.comm_axis;
+  if (plan.kind == HaloPlan::PACKED) launchMoves(plan.pre.data(), (int)plan.pre.size(), bufs, es, stream, &h->tuning);
+  haloExchange(h, gd, x, backend, stream);
+  if (plan.kind == HaloPlan::PACKED) launchMoves(plan.post.data(), (int)plan.post.size(), bufs, es, stream, &h->tuning);
+}
+
+}  // namespace cudecomp

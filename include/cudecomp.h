@@ -1,0 +1,273 @@
+/*
+ * cudecomp.h -- C API of the MI355X-native pencil-decomposition library.
+ *
+ * Drop-in boundary: the symbol names, enum values and struct layouts below are the ones
+ * NVIDIA/cuDecomp v0.7.0 exports (reference include/cudecomp.h:48-717), so a solver written
+ * against cuDecomp re-links against this library without source changes.  Behavioural notes that
+ * differ from the reference (the transports behind each backend enum on an xGMI node) are in
+ * DESIGN.md / INTEGRATION.md; everything observable through this header is kept identical.
+ *
+ * Conventions (same as the reference):
+ *   - all extents / halos / padding / periods arrays are in GLOBAL axis order [X, Y, Z];
+ *     cudecompPencilInfo_t.shape/lo/hi are in MEMORY order (see .order);
+ *   - array arguments documented as optional may be NULL (= all zero / all false);
+ *   - input == output selects the in-place algorithm;
+ *   - functions return CUDECOMP_RESULT_SUCCESS or an error code and never throw; a diagnostic
+ *     "CUDECOMP:ERROR: file:line kind (detail)" goes to stderr;
+ *   - grid-descriptor create/destroy, cudecompMalloc/Free and all transposes / halo updates are
+ *     collective over the communicator given to cudecompInit;
+ *   - GPU work is enqueued on the caller's stream.
+ */
+#ifndef CUDECOMP_H
+#define CUDECOMP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <hip/hip_runtime_api.h>
+
+#if defined(CUDECOMP_USE_MPI_HEADER)
+#include <mpi.h>
+#elif !defined(MPI_VERSION)
+#include "cudecomp_mpi_compat.h"
+#endif
+
+#include "cudecomp_version.h"
+
+/* Source compatibility for callers that still spell the stream type the CUDA way.  hipStream_t and
+ * cudaStream_t are both opaque pointers, so the ABI is unchanged (reference cudecomp.h:30,548). */
+#if defined(CUDECOMP_DECLARE_CUDA_STREAM_ALIAS) && !defined(__CUDA_RUNTIME_H__)
+typedef hipStream_t cudaStream_t;
+#endif
+
+/* struct header tags (reference cudecomp.h:36-38) */
+#define CUDECOMP_GRID_DESC_CONFIG_MAGIC INT32_C(0x434f4e46)
+#define CUDECOMP_GRID_DESC_AUTOTUNE_OPTIONS_MAGIC INT32_C(0x4155544f)
+#define CUDECOMP_PENCIL_INFO_MAGIC INT32_C(0x50494e46)
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (values fixed by the reference, cudecomp.h:48-113) ------------------------------- */
+
+/* Transpose transports.  On MI355X: NCCL* = RCCL over xGMI; MPI_* = ROCm-aware MPI in the MPI build,
+ * otherwise the intra-node xGMI peer-copy transport; NVSHMEM* = one-sided xGMI peer writes into
+ * cudecompMalloc'ed (IPC-mapped) workspaces. */
+typedef enum {
+  CUDECOMP_TRANSPOSE_COMM_MPI_P2P = 1,
+  CUDECOMP_TRANSPOSE_COMM_MPI_P2P_PL = 2,
+  CUDECOMP_TRANSPOSE_COMM_MPI_A2A = 3,
+  CUDECOMP_TRANSPOSE_COMM_NCCL = 4,
+  CUDECOMP_TRANSPOSE_COMM_NCCL_PL = 5,
+  CUDECOMP_TRANSPOSE_COMM_NVSHMEM = 6,
+  CUDECOMP_TRANSPOSE_COMM_NVSHMEM_PL = 7,
+  CUDECOMP_TRANSPOSE_COMM_NVSHMEM_SM = 8
+} cudecompTransposeCommBackend_t;
+
+typedef enum {
+  CUDECOMP_HALO_COMM_MPI = 1,
+  CUDECOMP_HALO_COMM_MPI_BLOCKING = 2,
+  CUDECOMP_HALO_COMM_NCCL = 3,
+  CUDECOMP_HALO_COMM_NVSHMEM = 4,
+  CUDECOMP_HALO_COMM_NVSHMEM_BLOCKING = 5
+} cudecompHaloCommBackend_t;
+
+typedef enum {
+  CUDECOMP_FLOAT = -1,
+  CUDECOMP_DOUBLE = -2,
+  CUDECOMP_FLOAT_COMPLEX = -3, /* interleaved re,im */
+  CUDECOMP_DOUBLE_COMPLEX = -4
+} cudecompDataType_t;
+
+typedef enum { CUDECOMP_AUTOTUNE_GRID_TRANSPOSE = 0, CUDECOMP_AUTOTUNE_GRID_HALO = 1 } cudecompAutotuneGridMode_t;
+
+typedef enum {
+  CUDECOMP_RANK_ORDER_DEFAULT = 0, /* row-major unless CUDECOMP_USE_COL_MAJOR_RANK_ORDER=1 (deprecated) */
+  CUDECOMP_RANK_ORDER_ROW_MAJOR = 1,
+  CUDECOMP_RANK_ORDER_COL_MAJOR = 2
+} cudecompRankOrder_t;
+
+typedef enum {
+  CUDECOMP_RESULT_SUCCESS = 0,
+  CUDECOMP_RESULT_INVALID_USAGE = 1,
+  CUDECOMP_RESULT_NOT_SUPPORTED = 2,
+  CUDECOMP_RESULT_INTERNAL_ERROR = 3,
+  CUDECOMP_RESULT_CUDA_ERROR = 4,     /* HIP runtime error */
+  CUDECOMP_RESULT_CUTENSOR_ERROR = 5, /* never produced: permutes are native kernels */
+  CUDECOMP_RESULT_MPI_ERROR = 6,      /* MPI or bootstrap error */
+  CUDECOMP_RESULT_NCCL_ERROR = 7,     /* RCCL error */
+  CUDECOMP_RESULT_NVSHMEM_ERROR = 8,  /* xGMI peer-transport error */
+  CUDECOMP_RESULT_NVML_ERROR = 9      /* never produced */
+} cudecompResult_t;
+
+/* ---- opaque objects ---------------------------------------------------------------------- */
+typedef struct cudecompHandle* cudecompHandle_t;
+typedef struct cudecompGridDesc* cudecompGridDesc_t;
+
+/* ---- versioned POD structs (sizes 104 / 320 / 96 bytes; reference src/cudecomp.cc:216,242,268) */
+
+typedef struct {
+  int64_t struct_size;
+  int32_t magic;
+  int32_t version;
+
+  int32_t gdims[3];      /* global grid */
+  int32_t gdims_dist[3]; /* grid used for distribution (0 = gdims); surplus goes to the last rank */
+  int32_t pdims[2];      /* process grid; {0,0} = autotune */
+  cudecompRankOrder_t rank_order;
+
+  cudecompTransposeCommBackend_t transpose_comm_backend; /* default MPI_P2P */
+  bool transpose_axis_contiguous[3];                      /* pencil axis fastest in memory */
+  int32_t transpose_mem_order[3][3];                      /* [axis][memory position], -1 = unset */
+
+  cudecompHaloCommBackend_t halo_comm_backend; /* default MPI */
+} cudecompGridDescConfig_t;
+
+typedef struct {
+  int64_t struct_size;
+  int32_t magic;
+  int32_t version;
+
+  int32_t n_warmup_trials; /* 3 */
+  int32_t n_trials;        /* 5 */
+  cudecompAutotuneGridMode_t grid_mode;
+  cudecompDataType_t dtype; /* CUDECOMP_DOUBLE */
+  bool allow_uneven_decompositions;
+  bool disable_mpi_backends;
+  bool disable_nccl_backends;
+  bool disable_nvshmem_backends;
+  double skip_threshold; /* skip a configuration if skip_threshold * t_first_trial > t_best */
+
+  bool autotune_transpose_backend;
+  bool transpose_use_inplace_buffers[4]; /* XToY, YToZ, ZToY, YToX */
+  double transpose_op_weights[4];
+  int32_t transpose_input_halo_extents[4][3];
+  int32_t transpose_output_halo_extents[4][3];
+  int32_t transpose_input_padding[4][3];
+  int32_t transpose_output_padding[4][3];
+
+  bool autotune_halo_backend;
+  int32_t halo_extents[3];
+  bool halo_periods[3];
+  int32_t halo_axis;
+  int32_t halo_padding[3];
+} cudecompGridDescAutotuneOptions_t;
+
+typedef struct {
+  int64_t struct_size;
+  int32_t magic;
+  int32_t version;
+
+  int32_t shape[3];        /* memory order, including halos and padding */
+  int32_t lo[3];           /* memory order, interior lower bound (global coordinate) */
+  int32_t hi[3];           /* memory order, interior upper bound (inclusive) */
+  int32_t order[3];        /* order[i] = global axis stored at memory position i (0 = fastest) */
+  int32_t halo_extents[3]; /* global order */
+  int32_t padding[3];      /* global order */
+  int64_t size;            /* number of elements, including halos and padding */
+} cudecompPencilInfo_t;
+
+/* ---- library / grid-descriptor lifetime --------------------------------------------------- */
+cudecompResult_t cudecompInit(cudecompHandle_t* handle, MPI_Comm mpi_comm);
+cudecompResult_t cudecompInit_F(cudecompHandle_t* handle, MPI_Fint mpi_comm_f);
+cudecompResult_t cudecompFinalize(cudecompHandle_t handle);
+
+cudecompResult_t cudecompGridDescCreateVersioned(cudecompHandle_t handle, cudecompGridDesc_t* grid_desc,
+                                                 cudecompGridDescConfig_t* config, int64_t config_struct_size,
+                                                 int32_t config_version,
+                                                 const cudecompGridDescAutotuneOptions_t* options,
+                                                 int64_t options_struct_size, int32_t options_version);
+cudecompResult_t cudecompGridDescDestroy(cudecompHandle_t handle, cudecompGridDesc_t grid_desc);
+cudecompResult_t cudecompGridDescConfigSetDefaultsVersioned(cudecompGridDescConfig_t* config, int64_t struct_size,
+                                                            int32_t version);
+cudecompResult_t cudecompGridDescAutotuneOptionsSetDefaultsVersioned(cudecompGridDescAutotuneOptions_t* options,
+                                                                     int64_t struct_size, int32_t version);
+cudecompResult_t cudecompGetGridDescConfigVersioned(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
+                                                    cudecompGridDescConfig_t* config, int64_t struct_size,
+                                                    int32_t version);
+
+/* ---- queries ------------------------------------------------------------------------------ */
+cudecompResult_t cudecompGetPencilInfoVersioned(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
+                                                cudecompPencilInfo_t* pencil_info, int64_t pencil_info_struct_size,
+                                                int32_t pencil_info_version, int32_t axis, const int32_t halo_extents[],
+                                                const int32_t padding[]);
+/* sizes are in ELEMENTS of the dtype used later */
+cudecompResult_t cudecompGetTransposeWorkspaceSize(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
+                                                   int64_t* workspace_size);
+cudecompResult_t cudecompGetHaloWorkspaceSize(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t axis,
+                                              const int32_t halo_extents[], int64_t* workspace_size);
+cudecompResult_t cudecompGetDataTypeSize(cudecompDataType_t dtype, int64_t* dtype_size);
+cudecompResult_t cudecompGetShiftedRank(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t axis,
+                                        int32_t dim, int32_t displacement, bool periodic, int32_t* shifted_rank);
+const char* cudecompTransposeCommBackendToString(cudecompTransposeCommBackend_t comm_backend);
+const char* cudecompHaloCommBackendToString(cudecompHaloCommBackend_t comm_backend);
+
+/* ---- workspace allocation (collective) ------------------------------------------------------ */
+cudecompResult_t cudecompMalloc(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void** buffer,
+                                size_t buffer_size_bytes);
+cudecompResult_t cudecompFree(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* buffer);
+
+/* ---- transposes (collective) ---------------------------------------------------------------- */
+cudecompResult_t cudecompTransposeXToY(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* output,
+                                       void* work, cudecompDataType_t dtype, const int32_t input_halo_extents[],
+                                       const int32_t output_halo_extents[], const int32_t input_padding[],
+                                       const int32_t output_padding[], hipStream_t stream);
+cudecompResult_t cudecompTransposeYToZ(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* output,
+                                       void* work, cudecompDataType_t dtype, const int32_t input_halo_extents[],
+                                       const int32_t output_halo_extents[], const int32_t input_padding[],
+                                       const int32_t output_padding[], hipStream_t stream);
+cudecompResult_t cudecompTransposeZToY(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* output,
+                                       void* work, cudecompDataType_t dtype, const int32_t input_halo_extents[],
+                                       const int32_t output_halo_extents[], const int32_t input_padding[],
+                                       const int32_t output_padding[], hipStream_t stream);
+cudecompResult_t cudecompTransposeYToX(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* output,
+                                       void* work, cudecompDataType_t dtype, const int32_t input_halo_extents[],
+                                       const int32_t output_halo_extents[], const int32_t input_padding[],
+                                       const int32_t output_padding[], hipStream_t stream);
+
+/* ---- halo updates (collective); dim = global axis whose halos are exchanged ------------------ */
+cudecompResult_t cudecompUpdateHalosX(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* work,
+                                      cudecompDataType_t dtype, const int32_t halo_extents[], const bool halo_periods[],
+                                      int32_t dim, const int32_t padding[], hipStream_t stream);
+cudecompResult_t cudecompUpdateHalosY(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* work,
+                                      cudecompDataType_t dtype, const int32_t halo_extents[], const bool halo_periods[],
+                                      int32_t dim, const int32_t padding[], hipStream_t stream);
+cudecompResult_t cudecompUpdateHalosZ(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* work,
+                                      cudecompDataType_t dtype, const int32_t halo_extents[], const bool halo_periods[],
+                                      int32_t dim, const int32_t padding[], hipStream_t stream);
+
+/* ---- header-only wrappers that bind the caller's struct sizes / versions --------------------- */
+static inline cudecompResult_t cudecompGridDescConfigSetDefaults(cudecompGridDescConfig_t* config) {
+  return cudecompGridDescConfigSetDefaultsVersioned(config, (int64_t)sizeof(cudecompGridDescConfig_t),
+                                                    CUDECOMP_GRID_DESC_CONFIG_VERSION);
+}
+static inline cudecompResult_t cudecompGridDescAutotuneOptionsSetDefaults(cudecompGridDescAutotuneOptions_t* options) {
+  return cudecompGridDescAutotuneOptionsSetDefaultsVersioned(
+      options, (int64_t)sizeof(cudecompGridDescAutotuneOptions_t), CUDECOMP_GRID_DESC_AUTOTUNE_OPTIONS_VERSION);
+}
+static inline cudecompResult_t cudecompGridDescCreate(cudecompHandle_t handle, cudecompGridDesc_t* grid_desc,
+                                                      cudecompGridDescConfig_t* config,
+                                                      const cudecompGridDescAutotuneOptions_t* options) {
+  return cudecompGridDescCreateVersioned(handle, grid_desc, config, (int64_t)sizeof(cudecompGridDescConfig_t),
+                                         CUDECOMP_GRID_DESC_CONFIG_VERSION, options,
+                                         options ? (int64_t)sizeof(cudecompGridDescAutotuneOptions_t) : (int64_t)0,
+                                         options ? CUDECOMP_GRID_DESC_AUTOTUNE_OPTIONS_VERSION : (int32_t)0);
+}
+static inline cudecompResult_t cudecompGetGridDescConfig(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
+                                                         cudecompGridDescConfig_t* config) {
+  return cudecompGetGridDescConfigVersioned(handle, grid_desc, config, (int64_t)sizeof(cudecompGridDescConfig_t),
+                                            CUDECOMP_GRID_DESC_CONFIG_VERSION);
+}
+static inline cudecompResult_t cudecompGetPencilInfo(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
+                                                     cudecompPencilInfo_t* pencil_info, int32_t axis,
+                                                     const int32_t halo_extents[], const int32_t padding[]) {
+  return cudecompGetPencilInfoVersioned(handle, grid_desc, pencil_info, (int64_t)sizeof(cudecompPencilInfo_t),
+                                        CUDECOMP_PENCIL_INFO_VERSION, axis, halo_extents, padding);
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDECOMP_H */

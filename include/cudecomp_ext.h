@@ -1,0 +1,75 @@
+/*
+ * cudecomp_ext.h -- entry points of libcudecomp.so that are NOT part of the cuDecomp API.
+ *
+ * They exist for test harnesses and tools: (1) running one strided block move through the HIP kernel
+ * layer, so kernel parity can be tested shape by shape; (2) reading the plan the library would execute
+ * for a transpose / halo update as plain data, so the host logic can be checked without a GPU (the
+ * multi-process CPU tests execute these plans with numpy + torch.distributed/gloo and compare against
+ * the oracle).  Solvers never need this header.
+ */
+#ifndef CUDECOMP_EXT_H
+#define CUDECOMP_EXT_H
+
+#include "cudecomp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUDECOMP_EXT_MAX_MEMBERS 64
+
+/* dst[dst_off + k0*ds[0] + k1*ds[1] + k2*ds[2]] = src[src_off + k0*ss[0] + k1*ss[1] + k2*ss[2]], in elements.
+ * Buffers: 0 = input pencil, 1 = output pencil, 2 = workspace. */
+typedef struct {
+  int32_t src_buf, dst_buf;
+  int64_t src_off, dst_off;
+  int64_t extent[3], ss[3], ds[3];
+  int32_t peer, reserved;
+} cudecompExtMove_t;
+
+typedef struct {
+  int32_t noop;     /* nothing to do */
+  int32_t exchange; /* an all-to-all happens between pack and unpack */
+  int32_t comm_axis /* 0 column, 1 row */, nranks, comm_rank;
+  int32_t send_buf, recv_buf;
+  int32_t n_pack, n_unpack, reserved;
+  int64_t send_base, recv_base; /* elements */
+  int64_t send_cnt[CUDECOMP_EXT_MAX_MEMBERS], send_off[CUDECOMP_EXT_MAX_MEMBERS];
+  int64_t recv_cnt[CUDECOMP_EXT_MAX_MEMBERS], recv_off[CUDECOMP_EXT_MAX_MEMBERS];
+  int64_t remote_recv_off[CUDECOMP_EXT_MAX_MEMBERS];
+  int32_t member_global_rank[CUDECOMP_EXT_MAX_MEMBERS];
+  int32_t schedule_dst[CUDECOMP_EXT_MAX_MEMBERS];
+  cudecompExtMove_t pack[CUDECOMP_EXT_MAX_MEMBERS];
+  cudecompExtMove_t unpack[CUDECOMP_EXT_MAX_MEMBERS];
+} cudecompExtTransposePlan_t;
+
+typedef struct {
+  int32_t kind; /* 0 none, 1 periodic self copy, 2 packed, 3 direct */
+  int32_t comm_axis, neighbor[2];
+  int32_t xbuf, n_pre, n_post, reserved;
+  int64_t face_elements, send_off[2], recv_off[2];
+  cudecompExtMove_t pre[2], post[2];
+} cudecompExtHaloPlan_t;
+
+/* op: 0 XToY, 1 YToZ, 2 ZToY, 3 YToX.  The plan is the one cudecompTranspose* would run for the grid
+ * descriptor's backend (or for `backend_override` if non-zero). */
+cudecompResult_t cudecompExtGetTransposePlan(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t op,
+                                             const int32_t input_halo_extents[], const int32_t output_halo_extents[],
+                                             const int32_t input_padding[], const int32_t output_padding[],
+                                             bool inplace, int32_t backend_override,
+                                             cudecompExtTransposePlan_t* plan);
+cudecompResult_t cudecompExtGetHaloPlan(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t axis,
+                                        const int32_t halo_extents[], const bool halo_periods[], int32_t dim,
+                                        const int32_t padding[], int32_t backend_override, cudecompExtHaloPlan_t* plan);
+
+/* Run one block move on the GPU (src/dst are device pointers, strides in elements of es bytes).
+ * force_generic != 0 selects the element-wise fallback kernel.  *kernel_class (optional) receives the
+ * kernel flavour used: 0 rows, 1 LDS transpose, 2 generic. */
+cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const int64_t extent[3],
+                                   const int64_t ss[3], const int64_t ds[3], int32_t force_generic,
+                                   int32_t* kernel_class, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,23 @@
+/*
+ * cudecomp_mpi_compat.h -- stand-in for the three MPI names cudecomp.h needs when the caller is
+ * not compiled against an MPI installation (ctypes harnesses, torchrun-launched benchmarks).
+ *
+ * The typedefs follow the MPICH ABI (MPI_Comm is an int handle, MPI_COMM_WORLD == 0x44000000) so
+ * that a libcudecomp.so built without MPI can also be called from an MPICH program passing
+ * MPI_COMM_WORLD.  Such a library ignores everything about the communicator except that it is the
+ * world: ranks are discovered from the launcher's environment ("Bootstrap").
+ * Programs that need sub-communicators or Open MPI's pointer-typed MPI_Comm link the MPI build of
+ * the library (make MPI=1) and include the real <mpi.h> before cudecomp.h.
+ */
+#ifndef CUDECOMP_MPI_COMPAT_H
+#define CUDECOMP_MPI_COMPAT_H
+
+#ifndef MPI_VERSION /* a real <mpi.h> was not included */
+typedef int MPI_Comm;
+typedef int MPI_Fint;
+#define MPI_COMM_WORLD ((MPI_Comm)0x44000000)
+#define MPI_COMM_NULL ((MPI_Comm)0x04000000)
+#define CUDECOMP_MPI_COMPAT 1
+#endif
+
+#endif

@@ -1,0 +1,140 @@
+"""Per-rank test bodies run by tests/mp.py (and directly, for single-rank cases)."""
+import ctypes as C
+
+import numpy as np
+
+import cudecomp_amd as cd
+from oracle import oracle as orc
+
+
+def _grid_and_handle(args):
+    h = cd.cudecompInit()
+    cfg = cd.make_config(args["gdims"], args["pdims"], gdims_dist=args.get("gdims_dist"),
+                         rank_order=args.get("rank_order", 0), axis_contiguous=args.get("ac", (0, 0, 0)),
+                         mem_order=args.get("mem_order"), transpose_backend=args.get("transpose_backend"),
+                         halo_backend=args.get("halo_backend"))
+    gd = cd.cudecompGridDescCreate(h, cfg)
+    return h, gd
+
+
+def index_queries(rank, nranks, args):
+    """Pencil infos, shifted ranks and workspace sizes of this rank through the C ABI."""
+    h, gd = _grid_and_handle(args)
+    out = {"rank": rank, "pencil": [], "shifted": [], "config_pdims": None}
+    for axis in range(3):
+        out["pencil"].append(cd.cudecompGetPencilInfo(h, gd, axis, args.get("halo"), args.get("padding")).as_dict())
+    for q in args.get("shifted_queries", []):
+        out["shifted"].append(cd.cudecompGetShiftedRank(h, gd, q["axis"], q["dim"], q["displacement"], q["periodic"]))
+    out["transpose_ws"] = cd.cudecompGetTransposeWorkspaceSize(h, gd)
+    if args.get("halo"):
+        out["halo_ws"] = [cd.cudecompGetHaloWorkspaceSize(h, gd, a, args["halo"]) for a in range(3)]
+    c = cd.cudecompGetGridDescConfig(h, gd)
+    out["config_pdims"] = [c.pdims[0], c.pdims[1]]
+    out["config_rank_order"] = c.rank_order
+    cd.cudecompGridDescDestroy(h, gd)
+    cd.cudecompFinalize(h)
+    return out
+
+
+# ---- numpy execution of the PRODUCT's plans (host-logic check, no GPU) -------------------------------
+def _view(buf, off, extent, strides):
+    es = buf.itemsize
+    return np.lib.stride_tricks.as_strided(buf[off:], shape=tuple(int(e) for e in extent)[::-1],
+                                           strides=tuple(int(s) * es for s in strides)[::-1])
+
+
+def run_moves(moves, n, bufs):
+    for i in range(n):
+        m = moves[i]
+        if 0 in list(m.extent):
+            continue
+        src = _view(bufs[m.src_buf], m.src_off, m.extent, m.ss)
+        dst = _view(bufs[m.dst_buf], m.dst_off, m.extent, m.ds)
+        dst[...] = src.copy()
+
+
+def plan_transpose_gloo(rank, nranks, args):
+    """Execute the product's transpose plans with numpy + gloo send/recv and check them against the analytic
+    oracle, for a full X->Y->Z->Y->X chain (tests/cc/transpose_test.cc:516-559)."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=nranks)
+    h, gd = _grid_and_handle(args)
+    kind = args.get("kind", 1)
+    dt = orc.KINDS[kind][0]
+    g = orc.Grid(args["gdims"], args["pdims"], gdims_dist=args.get("gdims_dist"),
+                 rank_order=args.get("rank_order", 0), axis_contiguous=args.get("ac", (0, 0, 0)),
+                 mem_order=args.get("mem_order"))
+    halos, pads = args.get("halos", [(0, 0, 0)] * 3), args.get("pads", [(0, 0, 0)] * 3)
+    pin = [cd.cudecompGetPencilInfo(h, gd, ax, halos[ax], pads[ax]) for ax in range(3)]
+    opin = [g.pencil_info(rank, ax, halos[ax], pads[ax]) for ax in range(3)]
+    for ax in range(3):
+        assert pin[ax].as_dict() == opin[ax].as_dict(), "pencil info differs from the oracle"
+    wsz = cd.cudecompGetTransposeWorkspaceSize(h, gd)
+    assert wsz == g.transpose_workspace_size()
+    nel = max(p.size for p in pin)
+    failures = []
+    for backend in args.get("backends", [cd.TRANSPOSE_COMM_NCCL]):
+        for oop in (True, False):
+            a = np.zeros(nel, dtype=dt)
+            b = np.zeros(nel, dtype=dt) if oop else a
+            a[:pin[0].size] = g.fill_pencil(opin[0], kind)
+            cur, nxt = a, b
+            for op in cd.OPS:
+                ai, ao = orc.OP_AXES[op]
+                work = np.zeros(wsz, dtype=dt)
+                plan = cd.cudecompExtGetTransposePlan(h, gd, op, halos[ai], halos[ao], pads[ai], pads[ao],
+                                                      inplace=not oop, backend_override=backend)
+                bufs = [cur, nxt, work]
+                if not plan.noop:
+                    run_moves(plan.pack, plan.n_pack, bufs)
+                    if plan.exchange:
+                        P = plan.nranks
+                        sendb, recvb = bufs[plan.send_buf], bufs[plan.recv_buf]
+                        # consistency of one-sided offsets: what I think member d's slot for me is must be what d thinks
+                        mine = torch.tensor([plan.recv_off[i] for i in range(P)], dtype=torch.int64)
+                        reqs, theirs = [], {}
+                        for d in range(P):
+                            gr = plan.member_global_rank[d]
+                            if gr == rank:
+                                continue
+                            theirs[d] = torch.zeros(P, dtype=torch.int64)
+                            reqs.append(dist.isend(mine.clone(), gr))
+                            reqs.append(dist.irecv(theirs[d], gr))
+                        for q in reqs:
+                            q.wait()
+                        for d, t in theirs.items():
+                            if int(t[plan.comm_rank]) != plan.remote_recv_off[d]:
+                                failures.append("%s: remote_recv_off[%d] mismatch" % (op, d))
+                        reqs, stage = [], {}
+                        for d in range(P):
+                            gr = plan.member_global_rank[d]
+                            so, sc = plan.send_base + plan.send_off[d], plan.send_cnt[d]
+                            ro, rc = plan.recv_base + plan.recv_off[d], plan.recv_cnt[d]
+                            if gr == rank:
+                                assert sc == rc
+                                recvb[ro:ro + rc] = sendb[so:so + sc].copy()
+                                continue
+                            s = torch.from_numpy(np.ascontiguousarray(sendb[so:so + sc]).view(np.uint8).copy())
+                            stage[d] = (torch.zeros(rc * a.itemsize, dtype=torch.uint8), ro, rc)
+                            if sc:
+                                reqs.append(dist.isend(s, gr))
+                            if rc:
+                                reqs.append(dist.irecv(stage[d][0], gr))
+                        for q in reqs:
+                            q.wait()
+                        for d, (t, ro, rc) in stage.items():
+                            recvb[ro:ro + rc] = t.numpy().view(dt)
+                    run_moves(plan.unpack, plan.n_unpack, bufs)
+                exp = g.fill_pencil(opin[ao], kind)
+                got = np.ascontiguousarray(nxt[:pin[ao].size])
+                bad = orc.compare_pencil(opin[ao], kind, exp, got, True)
+                if bad:
+                    failures.append("backend %d oop %s %s: mismatch at %d" % (backend, oop, op, bad - 1))
+                if oop:
+                    cur, nxt = nxt, cur
+    dist.barrier()
+    cd.cudecompGridDescDestroy(h, gd)
+    cd.cudecompFinalize(h)
+    dist.destroy_process_group()
+    return failures

@@ -1,0 +1,70 @@
+"""Launch a test body on N ranks (one process per rank), the way torchrun would: RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 in the environment.  libcudecomp.so's TCP bootstrap and torch.distributed (gloo)
+both rendezvous from these.
+
+    results = run_ranks(4, "tests.bodies", "pencil_info_golden", {"variant": "row_major"})
+
+Each rank runs  <module>.<func>(rank, nranks, args)  and must return a JSON-serialisable value; an
+exception (or a non-zero exit) on any rank fails the launch.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None):
+    port_a, port_b = free_port(), free_port()
+    outdir = tempfile.mkdtemp(prefix="cudecomp_mp_")
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "WORLD_SIZE": str(nranks), "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port_a), "CUDECOMP_BOOTSTRAP_PORT": str(port_b),
+                    "CUDECOMP_BOOTSTRAP_TIMEOUT": "60", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "PYTHONPATH": ROOT + os.pathsep + env.get("PYTHONPATH", "")})
+        if extra_env:
+            env.update(extra_env)
+        out = os.path.join(outdir, "rank%d.json" % r)
+        cmd = [sys.executable, os.path.abspath(__file__), module, func, json.dumps(args or {}), out]
+        procs.append((subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), out))
+    results, failures = [], []
+    for r, (p, out) in enumerate(procs):
+        try:
+            log, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q, _ in procs:
+                if q.poll() is None:
+                    q.kill()
+            log, _ = p.communicate()
+            failures.append("rank %d timed out\n%s" % (r, log.decode(errors="replace")[-4000:]))
+            continue
+        if p.returncode != 0 or not os.path.exists(out):
+            failures.append("rank %d exit %s\n%s" % (r, p.returncode, log.decode(errors="replace")[-4000:]))
+        else:
+            with open(out) as f:
+                results.append(json.load(f))
+    if failures:
+        raise AssertionError("\n".join(failures))
+    return results
+
+
+if __name__ == "__main__":
+    import importlib
+    module, func, args, out = sys.argv[1:5]
+    rank, nranks = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    result = getattr(importlib.import_module(module), func)(rank, nranks, json.loads(args))
+    with open(out, "w") as f:
+        json.dump(result, f)

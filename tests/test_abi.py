@@ -1,0 +1,192 @@
+"""The C-ABI library: loads, exports every symbol the headers declare, struct layouts, constants, argument
+checking.  No GPU needed (no compute entry point is called with valid buffers)."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+import cudecomp_amd as cd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(cudecomp\w+)\s*\(", src))
+    inline = set(re.findall(r"static inline \w+\s+(cudecomp\w+)\s*\(", src))
+    return names - inline
+
+
+def test_library_exports_every_declared_symbol():
+    L = cd.lib()
+    declared = declared_functions("cudecomp.h")
+    assert declared == set(cd.API_SYMBOLS)
+    for name in sorted(declared | declared_functions("cudecomp_ext.h")):
+        assert hasattr(L, name), name
+    assert declared_functions("cudecomp_ext.h") == set(cd.EXT_SYMBOLS)
+
+
+def test_struct_layouts_match_reference_abi():
+    # reference src/cudecomp.cc:216,242,268 and the field offsets of include/cudecomp.h:128-238
+    assert C.sizeof(cd.GridDescConfig) == 104
+    assert C.sizeof(cd.GridDescAutotuneOptions) == 320
+    assert C.sizeof(cd.PencilInfo) == 96
+    assert cd.GridDescConfig.transpose_mem_order.offset == 60
+    assert cd.GridDescConfig.halo_comm_backend.offset == 96
+    assert cd.GridDescAutotuneOptions.skip_threshold.offset == 40
+    assert cd.GridDescAutotuneOptions.halo_padding.offset == 304
+    assert cd.PencilInfo.size.offset == 88
+
+
+def test_defaults_match_golden(golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, "api_constants.json")))
+    c = cd.cudecompGridDescConfigSetDefaults()
+    assert (c.struct_size, c.magic, c.version) == (104, cd.GRID_DESC_CONFIG_MAGIC, 1)
+    assert gold["config_defaults"]["transpose_comm_backend"] == "CUDECOMP_TRANSPOSE_COMM_MPI_P2P"
+    assert c.transpose_comm_backend == cd.TRANSPOSE_COMM_MPI_P2P
+    assert c.halo_comm_backend == cd.HALO_COMM_MPI and c.rank_order == cd.RANK_ORDER_DEFAULT
+    assert list(c.pdims) == [0, 0] and list(c.gdims) == [0, 0, 0] and list(c.gdims_dist) == [0, 0, 0]
+    assert not any(c.transpose_axis_contiguous)
+    assert all(v == -1 for row in c.transpose_mem_order for v in row)
+    o = cd.cudecompGridDescAutotuneOptionsSetDefaults()
+    d = gold["autotune_option_defaults"]
+    assert (o.struct_size, o.magic, o.version) == (320, cd.GRID_DESC_AUTOTUNE_OPTIONS_MAGIC, 1)
+    assert o.n_warmup_trials == int(d["n_warmup_trials"]) and o.n_trials == int(d["n_trials"])
+    assert o.grid_mode == cd.AUTOTUNE_GRID_TRANSPOSE and o.dtype == cd.DOUBLE
+    assert o.allow_uneven_decompositions and not o.disable_mpi_backends and not o.disable_nccl_backends
+    assert not o.disable_nvshmem_backends and o.skip_threshold == 0.0
+    assert not o.autotune_transpose_backend and not o.autotune_halo_backend and o.halo_axis == 0
+    assert list(o.transpose_op_weights) == [1.0] * 4 and not any(o.transpose_use_inplace_buffers)
+    for tbl in (o.transpose_input_halo_extents, o.transpose_output_halo_extents, o.transpose_input_padding,
+                o.transpose_output_padding):
+        assert all(v == 0 for row in tbl for v in row)
+    assert list(o.halo_extents) == [0, 0, 0] and not any(o.halo_periods) and list(o.halo_padding) == [0, 0, 0]
+
+
+def test_dtype_sizes_and_backend_strings(golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, "api_constants.json")))
+    enum = {"CUDECOMP_FLOAT": cd.FLOAT, "CUDECOMP_DOUBLE": cd.DOUBLE, "CUDECOMP_FLOAT_COMPLEX": cd.FLOAT_COMPLEX,
+            "CUDECOMP_DOUBLE_COMPLEX": cd.DOUBLE_COMPLEX}
+    for name, size in gold["dtype_sizes"].items():
+        assert cd.cudecompGetDataTypeSize(enum[name]) == size
+    for name, text in gold["transpose_backend_strings"].items():
+        assert cd.cudecompTransposeCommBackendToString(getattr(cd, name[len("CUDECOMP_"):])) == text
+    for name, text in gold["halo_backend_strings"].items():
+        assert cd.cudecompHaloCommBackendToString(getattr(cd, name[len("CUDECOMP_"):])) == text
+    assert cd.cudecompTransposeCommBackendToString(999) == "ERROR"
+    assert cd.cudecompHaloCommBackendToString(999) == "ERROR"
+    L = cd.lib()
+    n = C.c_int64()
+    assert L.cudecompGetDataTypeSize(cd.FLOAT, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetDataTypeSize(999, C.byref(n)) == cd.RESULT_INVALID_USAGE
+
+
+def test_setdefaults_and_init_reject_bad_arguments(capfd):
+    L = cd.lib()
+    assert L.cudecompGridDescConfigSetDefaultsVersioned(None, 104, 1) == cd.RESULT_INVALID_USAGE
+    c = cd.GridDescConfig()
+    assert L.cudecompGridDescConfigSetDefaultsVersioned(C.byref(c), 103, 1) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGridDescConfigSetDefaultsVersioned(C.byref(c), 104, 2) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGridDescAutotuneOptionsSetDefaultsVersioned(None, 320, 1) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompInit(None, cd.MPI_COMM_WORLD) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompFinalize(None) == cd.RESULT_INVALID_USAGE
+    err = capfd.readouterr().err
+    assert "CUDECOMP:ERROR:" in err and "Invalid usage." in err  # reference message convention
+
+
+@pytest.fixture()
+def handle():
+    h = cd.cudecompInit()
+    yield h
+    cd.cudecompFinalize(h)
+
+
+def test_grid_desc_create_validation(handle):
+    # reference tests/ctest/api_tests.cc (GridDescCreate suites): every malformed config is INVALID_USAGE
+    L = cd.lib()
+    gd = C.c_void_p()
+
+    def create(cfg, opt=None, size=104, ver=1):
+        return L.cudecompGridDescCreateVersioned(handle, C.byref(gd), C.byref(cfg), size, ver,
+                                                 C.byref(opt) if opt is not None else None,
+                                                 320 if opt is not None else 0, 1 if opt is not None else 0)
+
+    good = cd.make_config((8, 8, 8), (1, 1))
+    assert L.cudecompGridDescCreateVersioned(handle, None, C.byref(good), 104, 1, None, 0, 0) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGridDescCreateVersioned(handle, C.byref(gd), None, 104, 1, None, 0, 0) == cd.RESULT_INVALID_USAGE
+    assert create(good, size=103) == cd.RESULT_INVALID_USAGE
+    assert create(good, ver=2) == cd.RESULT_INVALID_USAGE
+    raw = cd.GridDescConfig()  # never initialised: wrong magic
+    assert create(raw) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (2, 1))  # product != nranks
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (-1, -1))
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (0, 0))  # autotune pdims needs options
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (1, 1), transpose_backend=99)
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (1, 1), halo_backend=99)
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (1, 1), rank_order=7)
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (1, 1), gdims_dist=(9, 8, 8))
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (1, 1))
+    bad.transpose_mem_order[0][0] = 0  # partially set
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    bad = cd.make_config((8, 8, 8), (1, 1), mem_order=((0, 1, 2), (0, 0, 2), (0, 1, 2)))
+    assert create(bad) == cd.RESULT_INVALID_USAGE
+    assert create(good) == cd.RESULT_SUCCESS
+    # create reports "default" fields back as defaults (in/out config)
+    assert list(good.gdims_dist) == [0, 0, 0] and good.transpose_mem_order[0][0] == -1
+    assert good.rank_order == cd.RANK_ORDER_ROW_MAJOR  # DEFAULT resolved
+    other = cd.cudecompInit()
+    assert L.cudecompGridDescDestroy(other, gd) == cd.RESULT_INVALID_USAGE  # belongs to another handle
+    assert L.cudecompGetGridDescConfigVersioned(other, gd, C.byref(cd.GridDescConfig()), 104, 1) == cd.RESULT_INVALID_USAGE
+    cd.cudecompFinalize(other)
+    cd.cudecompGridDescDestroy(handle, gd)
+    assert L.cudecompGridDescDestroy(handle, None) == cd.RESULT_INVALID_USAGE
+
+
+def test_query_argument_checks(handle):
+    L = cd.lib()
+    gd = cd.cudecompGridDescCreate(handle, cd.make_config((9, 10, 11), (1, 1)))
+    p = cd.PencilInfo()
+    i3 = (C.c_int32 * 3)
+    assert L.cudecompGetPencilInfoVersioned(handle, gd, None, 96, 1, 0, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetPencilInfoVersioned(handle, gd, C.byref(p), 95, 1, 0, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetPencilInfoVersioned(handle, gd, C.byref(p), 96, 2, 0, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetPencilInfoVersioned(handle, gd, C.byref(p), 96, 1, -1, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetPencilInfoVersioned(handle, gd, C.byref(p), 96, 1, 0, i3(-1, 0, 0), None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetPencilInfoVersioned(handle, gd, C.byref(p), 96, 1, 0, None, i3(0, -1, 0)) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetPencilInfoVersioned(handle, gd, C.byref(p), 96, 1, 0, i3(2**31 - 1, 0, 0), None) == cd.RESULT_INVALID_USAGE
+    n = C.c_int64()
+    assert L.cudecompGetTransposeWorkspaceSize(handle, gd, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetTransposeWorkspaceSize(handle, None, C.byref(n)) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetHaloWorkspaceSize(handle, gd, 0, None, C.byref(n)) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetHaloWorkspaceSize(handle, gd, 3, i3(1, 1, 1), C.byref(n)) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetHaloWorkspaceSize(handle, gd, 0, i3(1, 1, 1), None) == cd.RESULT_INVALID_USAGE
+    r = C.c_int32()
+    assert L.cudecompGetShiftedRank(handle, gd, 3, 0, 1, False, C.byref(r)) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetShiftedRank(handle, gd, 0, 3, 1, False, C.byref(r)) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompGetShiftedRank(handle, gd, 0, 1, 1, False, None) == cd.RESULT_INVALID_USAGE
+    # transposes / halos: argument validation happens before any device work
+    assert L.cudecompTransposeXToY(handle, gd, None, 1, 1, cd.FLOAT, None, None, None, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompTransposeXToY(handle, gd, 1, None, 1, cd.FLOAT, None, None, None, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompTransposeXToY(handle, gd, 1, 1, None, cd.FLOAT, None, None, None, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompTransposeYToZ(handle, gd, 1, 1, 1, 5, None, None, None, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompUpdateHalosX(handle, gd, 1, 1, cd.FLOAT, None, None, 0, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompUpdateHalosX(handle, gd, None, 1, cd.FLOAT, i3(1, 1, 1), None, 0, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompUpdateHalosX(handle, gd, 1, 1, cd.FLOAT, i3(1, 1, 1), None, 3, None, None) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompUpdateHalosX(handle, gd, None, None, cd.FLOAT, i3(0, 0, 0), None, 0, None, None) == cd.RESULT_SUCCESS
+    buf = C.c_void_p()
+    assert L.cudecompMalloc(handle, gd, None, 16) == cd.RESULT_INVALID_USAGE
+    assert L.cudecompMalloc(handle, gd, C.byref(buf), 0) == cd.RESULT_INVALID_USAGE
+    big = cd.cudecompGridDescCreate(handle, cd.make_config((2**31 - 1,) * 3, (1, 1)))
+    assert L.cudecompGetPencilInfoVersioned(handle, big, C.byref(p), 96, 1, 0, None, None) == cd.RESULT_INVALID_USAGE
+    cd.cudecompGridDescDestroy(handle, big)
+    cd.cudecompGridDescDestroy(handle, gd)
