@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline measurement on MI355X: wall time and effective bandwidth of one
+X->Y->Z->Y->X transpose cycle of a 1024^3 fp64 array (BASELINE.json), through libcudecomp.so's C ABI.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full cycle (4 transposes) on device-resident synthetic data.  The protocol is the reference
+autotuner's (warm-up cycles, then timed cycles bracketed by barriers + device syncs, max over ranks;
+reference src/autotune.cc:541-636).  Rank 0 prints ONE JSON line.
+
+  value        effective GB/s = 4 * global array bytes / cycle time (whole job), as SURVEY.md section 8(d)
+  roofline     dominant kernel of the cycle at this configuration vs the HBM roofline
+  cpu_baseline the CPU oracle (oracle/, a port of the reference semantics; the reference has no CPU path)
+               timed on one host core on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=1024, help="global grid is size^3")
+    ap.add_argument("--layout", choices=["contiguous", "default"], default="contiguous",
+                    help="contiguous: every pencil axis-contiguous (the layout of the reference's published "
+                         "1024-class numbers, every hop permutes); default: X fastest everywhere")
+    ap.add_argument("--backend", default="auto", help="auto | nccl | nccl_pl | peer | peer_pl")
+    ap.add_argument("--pdims", type=int, nargs=2, default=None)
+    ap.add_argument("--inplace", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="grid edge of the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def measured_traffic(layout):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, see profiles/*_pmc_summary.json); PMC collection cannot run inside the timed loop."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return int(json.load(f)["layouts"][layout]["hbm_traffic_bytes_per_launch"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
+def cpu_baseline(sample, layout):
+    """Oracle timed on this host: one X->Y->Z->Y->X cycle of a sample^3 fp64 array, 1x1 grid, same layout."""
+    import numpy as np
+    from oracle import oracle as orc
+    ac = (1, 1, 1) if layout == "contiguous" else (0, 0, 0)
+    g = orc.Grid((sample,) * 3, (1, 1), axis_contiguous=ac)
+    n = sample ** 3
+    rng = np.random.default_rng(0)
+    a, b = [rng.random(n)], [np.zeros(n)]
+    w = [np.zeros(g.transpose_workspace_size())]
+    t0 = time.perf_counter()
+    for op in ("XToY", "YToZ", "ZToY", "YToX"):
+        assert g.transpose(op, 1, a, b, w) == orc.OK
+        a, b = b, a
+    dt = time.perf_counter() - t0
+    return {"value": round(4 * n * 8 / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "%d^3 fp64 X->Y->Z->Y->X cycle, 1x1 grid, %s layout, out-of-place, %.1f s on one core"
+                      % (sample, layout, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import cudecomp_amd as cd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    torch.zeros(1, device="cuda")
+    if world > 1:
+        # control plane of the harness only (barrier, max over ranks); the library moves data itself over
+        # RCCL / xGMI and bootstraps from the same RANK / WORLD_SIZE / MASTER_* environment
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    n = args.size
+    ac = (1, 1, 1) if args.layout == "contiguous" else (0, 0, 0)
+    backends = {"nccl": cd.TRANSPOSE_COMM_NCCL, "nccl_pl": cd.TRANSPOSE_COMM_NCCL_PL,
+                "peer": cd.TRANSPOSE_COMM_NVSHMEM, "peer_pl": cd.TRANSPOSE_COMM_NVSHMEM_PL}
+    choice = args.backend if args.backend != "auto" else "nccl"
+    pdims = tuple(args.pdims) if args.pdims else (1, world)
+
+    h = cd.cudecompInit()
+    gd, used = None, None
+    for cand in ([choice] if args.backend != "auto" else ["nccl", "peer"]):
+        try:
+            cfg = cd.make_config((n, n, n), pdims, axis_contiguous=ac, transpose_backend=backends[cand])
+            gd = cd.cudecompGridDescCreate(h, cfg)
+            used = cand
+            break
+        except cd.CudecompError as e:
+            if rank == 0:
+                print("bench: backend %s unavailable (%s)" % (cand, e), file=sys.stderr)
+    if gd is None:
+        raise SystemExit("no usable transport")
+
+    es = 8
+    pinfo = [cd.cudecompGetPencilInfo(h, gd, ax) for ax in range(3)]
+    nel = max(p.size for p in pinfo)
+    wsz = cd.cudecompGetTransposeWorkspaceSize(h, gd)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    # synthetic payload: random 64-bit patterns (a transpose only relocates bits)
+    a = torch.randint(-2**62, 2**62, (nel,), dtype=torch.int64, device="cuda", generator=gen)
+    b = a if args.inplace else torch.zeros_like(a)
+    work = cd.cudecompMalloc(h, gd, wsz * es)
+    stream = torch.cuda.current_stream().cuda_stream
+    checksum0 = int(a[:pinfo[0].size].sum())
+
+    def cycle():
+        cur, nxt = a, b
+        for op in cd.OPS:
+            cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DOUBLE, stream=stream)
+            if not args.inplace:
+                cur, nxt = nxt, cur
+
+    for _ in range(args.warmup):
+        cycle()
+    torch.cuda.synchronize()
+    # per-op split (outside the timed region)
+    op_ms = []
+    cur, nxt = a, b
+    for op in cd.OPS:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DOUBLE, stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        op_ms.append(e0.elapsed_time(e1))
+        if not args.inplace:
+            cur, nxt = nxt, cur
+
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        cycle()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+    ok = int(a[:pinfo[0].size].sum()) == checksum0  # an even number of cycles... every cycle returns the input
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        global_bytes = n ** 3 * es
+        value = 4 * global_bytes / (ms_per_step * 1e-3) / 1e9
+        # dominant kernel: at 1x1 every hop is ONE launch that reads and writes each element of the pencil once
+        # (LDS-tiled permutation for the contiguous layout, streaming row copy for the default layout)
+        launches = 4 * args.steps
+        alg_bytes = 2 * pinfo[0].size * es
+        avg_ms = dev_ms / launches
+        roof = None
+        if world == 1:
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": measured_traffic(args.layout) if n == 1024 else None,
+                    "kernel": "transpose_kernel<8,2,64,64>" if args.layout == "contiguous" else "rows_kernel<16>",
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4)}
+        out = {
+            "metric": "transpose cycle (X->Y->Z->Y->X) effective bandwidth, %d^3 fp64" % n,
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d^3 fp64 X->Y->Z->Y->X transpose cycle, %dx%d process grid, %s layout, %s"
+                                   % (n, pdims[0], pdims[1],
+                                      "all-axis-contiguous" if args.layout == "contiguous" else "default (X fastest)",
+                                      "in-place" if args.inplace else "out-of-place"),
+                       "pdims": list(pdims), "transport": used, "per_op_ms": [round(x, 4) for x in op_ms],
+                       "round_trip_checksum_ok": bool(ok)},
+            "roofline": roof,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.layout)
+        print(json.dumps(out))
+
+    cd.cudecompFree(h, gd, work)
+    cd.cudecompGridDescDestroy(h, gd)
+    cd.cudecompFinalize(h)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libcudecomp.so is missing (%s): build it with `make -C cudecomp_amd` or "
                               "__graft_entry__.build(); there is no fallback path" % LIB_PATH)
+        # torch ships its own copy of the HIP runtime under a different file name; whichever runtime is loaded
+        # first must serve both, so bring torch's in before our DT_NEEDED libamdhip64.so.7 gets resolved
+        # (two runtimes in one process corrupt the heap at exit).  A C/C++ solver never hits this.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         pi32 = C.POINTER(C.c_int32)

@@ -172,3 +172,17 @@ def peer_ranks(nranks, npergroup, rank, it):
     s, d = C.c_int(0), C.c_int(0)
     lib().orc_peer_ranks(nranks, npergroup, rank, it, C.byref(s), C.byref(d))
     return s.value, d.value
+
+
+def move3d_reference(src, dst, extent, ss, ds, src_off=0, dst_off=0):
+    """numpy restatement of one strided block move (the K1 copy of cudecomp_kernels.cuh:125-180 and the
+    cutensorPermute call of transpose.h:80-157 are both instances):
+        dst[dst_off + k0*ds0 + k1*ds1 + k2*ds2] = src[src_off + k0*ss0 + k1*ss1 + k2*ss2]
+    src/dst are 1-D numpy arrays of the element dtype; strides in elements."""
+    es = src.itemsize
+    shape = tuple(int(e) for e in extent)[::-1]
+    if 0 in shape:
+        return
+    sv = np.lib.stride_tricks.as_strided(src[src_off:], shape=shape, strides=tuple(int(s) * es for s in ss)[::-1])
+    dv = np.lib.stride_tricks.as_strided(dst[dst_off:], shape=shape, strides=tuple(int(s) * es for s in ds)[::-1])
+    dv[...] = sv

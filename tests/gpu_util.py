@@ -1,0 +1,30 @@
+"""Device-memory plumbing for the GPU tests: torch owns the buffers, libcudecomp.so does the work."""
+import numpy as np
+import torch
+
+from oracle import oracle as orc
+
+TORCH_DT = {0: torch.float32, 1: torch.float64, 2: torch.complex64, 3: torch.complex128}
+
+
+def to_device(arr):
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def to_host(t):
+    return t.detach().cpu().numpy()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def raw_bytes_dtype(es):
+    """An integer-viewable numpy dtype of es bytes (payload is opaque bytes)."""
+    return {4: np.uint32, 8: np.uint64, 16: np.complex128}[es]
+
+
+def random_payload(n, es, seed):
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, 2**32, size=n * (es // 4), dtype=np.uint32)
+    return raw.view(raw_bytes_dtype(es)) if es != 16 else raw.view(np.uint64).view(np.complex128)

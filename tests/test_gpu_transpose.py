@@ -1,0 +1,122 @@
+"""HIP transposes through the C ABI vs the oracle: the reference's ctest matrix (single rank in-process,
+2x2 / 3x1 / 1x4 as processes sharing the GPU over the xGMI peer transport), the legacy 36-memory-order
+sweep, and size-independent properties at the benchmark size."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+import cudecomp_amd as cd
+from tests import cases as K
+from tests import gpu_bodies as B
+from tests.mp import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+SINGLE = [c for c in K.ctest_transpose_cases(pdims_list=((1, 1),)) if tuple(c["pdims"]) == (1, 1)]
+
+
+@pytest.mark.parametrize("c", SINGLE, ids=K.case_id)
+def test_ctest_cases_single_rank(c):
+    assert B.single_transpose(0, 1, c) == []
+
+
+@pytest.mark.parametrize("mo", K.mem_order_combos(), ids=lambda m: "".join("".join(map(str, r)) for r in m))
+def test_all_mem_orders_single_rank(mo):
+    # legacy sweep shape scaled down; fp64 keeps 16-byte vector paths reachable (even extents) and the
+    # 9x10x11 run hits the scalar paths
+    for gdims, kind in (((16, 12, 20), 1), ((9, 10, 11), 0)):
+        args = {"gdims": gdims, "pdims": (1, 1), "mem_order": mo, "kind": kind}
+        assert B.transpose_chain(0, 1, args) == []
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_legacy_grid_single_rank(kind):
+    # tests/test_config.yaml:23-25: 128 x 124 x 132, default and axis-contiguous layouts, halos + padding
+    for ac in (K.DEFAULT_AC, K.ALL_AC):
+        args = {"gdims": (128, 124, 132), "pdims": (1, 1), "ac": ac, "kind": kind}
+        assert B.transpose_chain(0, 1, args) == []
+    args = {"gdims": (128, 124, 132), "pdims": (1, 1), "ac": K.ALL_AC, "kind": kind,
+            "halos": [(1, 1, 1), (0, 0, 0), (1, 1, 1)], "pads": [(0, 0, 0), (1, 1, 1), (0, 0, 0)]}
+    assert B.transpose_chain(0, 1, args) == []
+
+
+MULTI = [c for c in K.ctest_transpose_cases(pdims_list=((2, 2),)) if tuple(c["pdims"]) != (1, 1)]
+# a spread of the multi-rank matrix (every scenario, one dtype/op each) keeps GPU minutes bounded
+MULTI_PICK = {}
+for c in MULTI:
+    MULTI_PICK.setdefault((c["name"], c["op"], c["out_of_place"]), c)
+MULTI_PICK = [c for i, c in enumerate(MULTI_PICK.values()) if c["name"] != "BaselineDefaultLayout" or i % 2 == 0]
+
+
+def _by_nranks(cases):
+    groups = {}
+    for c in cases:
+        groups.setdefault(c["pdims"][0] * c["pdims"][1], []).append(c)
+    return groups
+
+
+@pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_MPI_P2P, cd.TRANSPOSE_COMM_NVSHMEM_PL],
+                         ids=["peer", "peer_pipelined"])
+def test_ctest_cases_multi_rank_peer_transport(backend):
+    # one process group per rank count runs the whole matrix (a group launch costs ~10 s of imports)
+    for n, cases in sorted(_by_nranks(MULTI_PICK).items()):
+        jobs = [{"fn": "single_transpose", "id": K.case_id(c), "args": dict(c, transpose_backend=backend)}
+                for c in cases]
+        for failures in run_ranks(n, "tests.gpu_bodies", "many", {"jobs": jobs}, timeout=600):
+            assert failures == []
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_cycle_multi_rank_peer_transport(n):
+    jobs = []
+    for pdims in [(2, 2), (1, 4), (4, 1), (2, 1), (1, 2)]:
+        if pdims[0] * pdims[1] != n:
+            continue
+        for ac, work, backend in ((K.DEFAULT_AC, "malloc", cd.TRANSPOSE_COMM_MPI_P2P),
+                                  (K.ALL_AC, "torch", cd.TRANSPOSE_COMM_MPI_A2A),
+                                  (K.ALL_AC, "malloc", cd.TRANSPOSE_COMM_NVSHMEM)):
+            jobs.append({"fn": "transpose_chain", "id": "P%dx%d_%s_%s" % (pdims[0], pdims[1], ac, work),
+                         "args": {"gdims": (32, 24, 40), "pdims": pdims, "ac": ac, "kind": 1, "work_alloc": work,
+                                  "transpose_backend": backend}})
+    for failures in run_ranks(n, "tests.gpu_bodies", "many", {"jobs": jobs}, timeout=600):
+        assert failures == []
+
+
+def test_rccl_backend_single_rank_world():
+    # RCCL path with a one-rank world: communicator creation is skipped, transposes are local
+    args = {"gdims": (16, 12, 20), "pdims": (1, 1), "ac": K.ALL_AC, "kind": 1, "transpose_backend": cd.TRANSPOSE_COMM_NCCL}
+    assert B.transpose_chain(0, 1, args) == []
+
+
+def test_round_trip_and_checksum_at_benchmark_size():
+    """1024^3 fp64 (BASELINE.json): X->Y->Z->Y->X reproduces the input bit for bit, and every intermediate
+    pencil holds a permutation of the input (wrapping 64-bit sum and xor of the raw words are invariant)."""
+    from tests import gpu_util as G
+    n = 1024
+    h = B._handle(0)
+    gd = cd.cudecompGridDescCreate(h, cd.make_config((n, n, n), (1, 1), axis_contiguous=(1, 1, 1)))
+    nel = n ** 3
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    a = torch.randint(-2**62, 2**62, (nel,), dtype=torch.int64, device="cuda", generator=g)
+    ref_sum, ref_xor = int(a.sum()), int(torch.bitwise_xor(a[::2], a[1::2]).sum())
+    keep = a.clone()
+    b = torch.zeros_like(a)
+    work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * 8)
+    cur, nxt = a, b
+    for op in cd.OPS:
+        cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DOUBLE, stream=G.stream_ptr())
+        torch.cuda.synchronize()
+        assert int(nxt.sum()) == ref_sum
+        cur, nxt = nxt, cur
+    assert torch.equal(cur, keep)
+    # spot-check the X->Y permutation against the index map: out[y + Y*(z + Z*x)] == in[x + X*(y + Y*z)]
+    cd.cudecompTranspose("XToY", h, gd, keep.data_ptr(), b.data_ptr(), work, cd.DOUBLE, stream=G.stream_ptr())
+    torch.cuda.synchronize()
+    idx = torch.randint(0, n, (3, 4096), device="cuda", generator=g)
+    x, y, z = idx[0], idx[1], idx[2]
+    assert torch.equal(b[y + n * (z + n * x)], keep[x + n * (y + n * z)])
+    cd.cudecompFree(h, gd, work)
+    cd.cudecompGridDescDestroy(h, gd)
