@@ -168,11 +168,9 @@ void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
   if (need_peer && !h->peer) h->peer = std::make_shared<PeerContext>(h);  // touches the device on first use only
 }
 
-void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes) {
-  const bool peer_backend = !transposeBackendIsRccl(gd->config.transpose_comm_backend) ||
-                            !haloBackendIsRccl(gd->config.halo_comm_backend);
+void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
   void* ptr = nullptr;
-  if (h->nranks > 1 && peer_backend) {
+  if (h->nranks > 1 && peer_capable) {
     // one-sided writes address the peer's workspace by offset: make it the same size everywhere
     bytes = (size_t)h->boot->allreduceMaxI64((int64_t)bytes);
     prepareTransports(h, false, true);
@@ -189,10 +187,21 @@ void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes) {
   return ptr;
 }
 
-void workspaceFree(cudecompHandle_t h, cudecompGridDesc_t, void* ptr) {
-  if (h->peer && h->peer->find(ptr) && h->peer->find(ptr)->base == ptr) h->peer->unregisterRegion(ptr);
+void workspaceFreeRaw(cudecompHandle_t h, void* ptr) {
+  if (h->peer) {
+    auto* r = h->peer->find(ptr);
+    if (r && r->base == ptr) h->peer->unregisterRegion(ptr);
+  }
   CD_CHECK_HIP(hipFree(ptr));
 }
+
+void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes) {
+  const bool peer_backend = !transposeBackendIsRccl(gd->config.transpose_comm_backend) ||
+                            !haloBackendIsRccl(gd->config.halo_comm_backend);
+  return workspaceAllocRaw(h, bytes, peer_backend);
+}
+
+void workspaceFree(cudecompHandle_t h, cudecompGridDesc_t, void* ptr) { workspaceFreeRaw(h, ptr); }
 
 // ================================================================================================
 // all-to-all

@@ -28,6 +28,9 @@ MPI_Comm commFromFortran(MPI_Fint f);
 void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer);
 
 void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes);  // collective
+// same, without a grid descriptor: peer_capable = map the buffer into the other ranks for one-sided writes
+void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable);
+void workspaceFreeRaw(cudecompHandle_t h, void* ptr);
 void workspaceFree(cudecompHandle_t h, cudecompGridDesc_t gd, void* ptr);       // collective
 
 struct ExchangeBuffers {

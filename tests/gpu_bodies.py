@@ -137,3 +137,32 @@ def many(rank, nranks, args):
         fails = globals()[job["fn"]](rank, nranks, job["args"])
         out.extend("%s: %s" % (job.get("id", job["fn"]), f) for f in fails)
     return out
+
+
+def autotune_then_cycle(rank, nranks, args):
+    """Grid + backend autotuning (cudecompGridDescCreate with options), then a checked transpose cycle and a
+    halo sweep with whatever was selected."""
+    h = _handle(rank)
+    cfg = cd.make_config(args["gdims"], args.get("pdims", (0, 0)), axis_contiguous=args.get("ac", (0, 0, 0)))
+    opt = cd.cudecompGridDescAutotuneOptionsSetDefaults()
+    opt.n_warmup_trials, opt.n_trials = 1, 2
+    opt.dtype = cd.DTYPE_OF_KIND[args.get("kind", 1)]
+    opt.autotune_transpose_backend = True
+    opt.autotune_halo_backend = bool(args.get("halo_backend_too", True))
+    opt.disable_nccl_backends = bool(args.get("disable_nccl", False))
+    opt.skip_threshold = args.get("skip_threshold", 0.0)
+    for i in range(3):
+        opt.halo_extents[i] = 1
+        opt.halo_periods[i] = True
+    if args.get("grid_mode_halo"):
+        opt.grid_mode = cd.AUTOTUNE_GRID_HALO
+    gd = cd.cudecompGridDescCreate(h, cfg, opt)
+    picked = {"pdims": [cfg.pdims[0], cfg.pdims[1]], "tb": cfg.transpose_comm_backend, "hb": cfg.halo_comm_backend}
+    q = cd.cudecompGetGridDescConfig(h, gd)
+    assert [q.pdims[0], q.pdims[1]] == picked["pdims"] and q.transpose_comm_backend == picked["tb"]
+    cd.cudecompGridDescDestroy(h, gd)
+    a = {"gdims": args["gdims"], "pdims": picked["pdims"], "ac": args.get("ac", (0, 0, 0)), "kind": args.get("kind", 1),
+         "transpose_backend": picked["tb"], "halo_backend": picked["hb"]}
+    fails = transpose_chain(rank, nranks, a)
+    fails += halo_sweep(rank, nranks, dict(a, halo=(1, 1, 1), periods=(1, 1, 1), axes=[0]))
+    return {"picked": picked, "failures": fails}

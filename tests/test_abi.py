@@ -190,3 +190,43 @@ def test_query_argument_checks(handle):
     assert L.cudecompGetPencilInfoVersioned(handle, big, C.byref(p), 96, 1, 0, None, None) == cd.RESULT_INVALID_USAGE
     cd.cudecompGridDescDestroy(handle, big)
     cd.cudecompGridDescDestroy(handle, gd)
+
+
+def test_autotune_candidate_filters(handle, monkeypatch):
+    # reference tests/ctest/api_tests.cc:319-443: environment filters are validated at grid-descriptor creation
+    L = cd.lib()
+    gd = C.c_void_p()
+    opt = cd.cudecompGridDescAutotuneOptionsSetDefaults()
+    opt.autotune_transpose_backend = True
+
+    def create(cfg, o):
+        return L.cudecompGridDescCreateVersioned(handle, C.byref(gd), C.byref(cfg), 104, 1, C.byref(o), 320, 1)
+
+    cfg = cd.make_config((8, 8, 8), (1, 1))
+    monkeypatch.setenv("CUDECOMP_AUTOTUNE_TRANSPOSE_BACKENDS", "NCCL,BOGUS")
+    assert create(cfg, opt) == cd.RESULT_INVALID_USAGE
+    monkeypatch.setenv("CUDECOMP_AUTOTUNE_TRANSPOSE_BACKENDS", "NCCL,")
+    assert create(cfg, opt) == cd.RESULT_INVALID_USAGE
+    monkeypatch.setenv("CUDECOMP_AUTOTUNE_TRANSPOSE_BACKENDS", "MPI_P2P,MPI_P2P_PL,MPI_A2A")
+    opt.disable_mpi_backends = True
+    assert create(cfg, opt) == cd.RESULT_INVALID_USAGE  # nothing left after the filters
+    opt.disable_mpi_backends = False
+    monkeypatch.setenv("CUDECOMP_AUTOTUNE_TRANSPOSE_BACKENDS",
+                       "^MPI_P2P,MPI_P2P_PL,MPI_A2A,NCCL,NCCL_PL,NVSHMEM,NVSHMEM_PL,NVSHMEM_SM")
+    assert create(cfg, opt) == cd.RESULT_INVALID_USAGE
+    monkeypatch.delenv("CUDECOMP_AUTOTUNE_TRANSPOSE_BACKENDS")
+    opt.autotune_transpose_backend = False
+    opt.autotune_halo_backend = True
+    monkeypatch.setenv("CUDECOMP_AUTOTUNE_HALO_BACKENDS", "MPI,NOPE")
+    assert create(cfg, opt) == cd.RESULT_INVALID_USAGE
+    monkeypatch.delenv("CUDECOMP_AUTOTUNE_HALO_BACKENDS")
+    opt.autotune_halo_backend = False
+    cfg0 = cd.make_config((8, 8, 8), (0, 0))
+    for bad in ("3", "2,1", "a,b", "1,2,3", "-1,4"):
+        monkeypatch.setenv("CUDECOMP_AUTOTUNE_P_ROW_RANGE", bad)
+        assert create(cfg0, opt) == cd.RESULT_INVALID_USAGE, bad
+    monkeypatch.setenv("CUDECOMP_AUTOTUNE_P_ROW_RANGE", "2,4")  # no grid of one rank has 2..4 rows
+    assert create(cfg0, opt) == cd.RESULT_INVALID_USAGE
+    monkeypatch.delenv("CUDECOMP_AUTOTUNE_P_ROW_RANGE")
+    opt.grid_mode = 7
+    assert create(cfg0, opt) in (cd.RESULT_INVALID_USAGE, cd.RESULT_CUDA_ERROR)
