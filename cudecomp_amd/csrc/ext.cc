@@ -150,7 +150,8 @@ cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const
     }
     void* bufs[3] = {const_cast<void*>(src), dst, nullptr};
     KernelTuning t;
-    if (force_generic) t.force_class = MOVE_GENERIC;
+    if (force_generic & 1) t.force_class = MOVE_GENERIC;
+    if (force_generic & 2) t.force_streaming = true;
     KernelStats st;
     launchMoves(&m, 1, bufs, es, stream, &t, &st);
     if (kernel_class) {

@@ -36,6 +36,7 @@ namespace {
 constexpr int kMaxBatch = 8;
 constexpr int kThreads = 256;
 constexpr int kRowsUnroll = 4;
+constexpr long long kStreamBytes = 32ll << 20;  // moves at least this large use non-temporal access
 
 struct DevMove {
   const char* src;
@@ -48,6 +49,7 @@ struct DevMove {
 struct Batch {
   int n;
   int p0[kMaxBatch];                      // kernel-specific small parameter
+  int p1[kMaxBatch];                      // second small parameter (transpose: XCD-contiguous tile walk)
   unsigned int first_block[kMaxBatch + 1];
   unsigned int t0[kMaxBatch];             // tiles along dim 0
   unsigned int t1[kMaxBatch];             // tiles along dim 1
@@ -85,6 +87,20 @@ template <> struct Lane<8, 2> {
   }
 };
 
+// Streaming (non-temporal) access for moves far larger than the caches: measured +3..15 % on the 1024^3
+// permutations (profiles/r01_tuning.md); small moves keep the default policy so a following kernel can
+// still find the data in L2 / Infinity Cache.
+template <bool STREAM, typename V>
+__device__ __forceinline__ V loadVec(const V* p) {
+  if constexpr (STREAM) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool STREAM, typename V>
+__device__ __forceinline__ void storeVec(V* p, const V& v) {
+  if constexpr (STREAM) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 __device__ __forceinline__ int findMove(const Batch& b, unsigned int block) {
   int mi = 0;
 #pragma unroll
@@ -97,7 +113,7 @@ __device__ __forceinline__ int findMove(const Batch& b, unsigned int block) {
 // rows_kernel: e[0] = vectors per row, e[1] = rows, e[2] = planes; ss/ds[1], [2] in vectors.
 // p0 = log2(lanes per row).  A workgroup covers (256 >> p0) * kRowsUnroll rows x (1 << p0) vectors.
 // ---------------------------------------------------------------------------------------------
-template <int VB>
+template <int VB, bool STREAM>
 __global__ __launch_bounds__(kThreads) void rows_kernel(const Batch b) {
   using V = Bytes<VB>;
   const int mi = findMove(b, blockIdx.x);
@@ -122,12 +138,61 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(const Batch b) {
 #pragma unroll
   for (int u = 0; u < kRowsUnroll; ++u) {
     const long long r = r0 + (long long)u * rb;
-    if (r < m.e[1]) v[u] = s[r * m.ss[1]];
+    if (r < m.e[1]) v[u] = loadVec<STREAM>(s + r * m.ss[1]);
   }
 #pragma unroll
   for (int u = 0; u < kRowsUnroll; ++u) {
     const long long r = r0 + (long long)u * rb;
-    if (r < m.e[1]) d[r * m.ds[1]] = v[u];
+    if (r < m.e[1]) storeVec<STREAM>(d + r * m.ds[1], v[u]);
+  }
+}
+
+template <int ES, int VW, int TI, int TJ, bool STREAM, bool GUARD>
+__device__ __forceinline__ void transposeTile(Bytes<ES>* tile, const Bytes<ES>* __restrict__ src,
+                                              Bytes<ES>* __restrict__ dst, long long i0, long long j0, long long ei,
+                                              long long ej, long long sj, long long di, int tid) {
+  using E = Bytes<ES>;
+  using V = Bytes<ES * VW>;
+  constexpr int TPR = TI / VW;         // lanes per source row segment
+  constexpr int RPP = kThreads / TPR;  // source rows per pass
+  constexpr int NP = TJ / RPP;         // load passes
+  constexpr int TPO = TJ / VW;         // lanes per destination row segment
+  constexpr int RPO = kThreads / TPO;  // destination rows per pass
+  constexpr int NPO = TI / RPO;        // store passes
+  constexpr int PITCH = TI + 1;
+  // ---- global -> registers (all loads issued before the first use) -> LDS, rows along i
+  {
+    const int li = (tid % TPR) * VW;
+    const int lj = tid / TPR;
+    const E* base = src + (j0 + lj) * sj + i0 + li;
+    V regs[NP] = {};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (!GUARD || (i0 + li < ei && j0 + lj + p * RPP < ej))
+        regs[p] = loadVec<STREAM>(reinterpret_cast<const V*>(base + (long long)(p * RPP) * sj));
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      E* row = tile + (lj + p * RPP) * PITCH + li;
+#pragma unroll
+      for (int v = 0; v < VW; ++v) row[v] = Lane<ES, VW>::get(regs[p], v);
+    }
+  }
+  __syncthreads();
+  // ---- LDS -> registers -> global, rows along j
+  {
+    const int lj = (tid % TPO) * VW;
+    const int li = tid / TPO;
+    E* base = dst + (i0 + li) * di + j0 + lj;
+#pragma unroll
+    for (int p = 0; p < NPO; ++p) {
+      const int ii = li + p * RPO;
+      V out;
+#pragma unroll
+      for (int v = 0; v < VW; ++v) Lane<ES, VW>::set(out, v, tile[(lj + v) * PITCH + ii]);
+      if (!GUARD || (i0 + ii < ei && j0 + lj < ej))
+        storeVec<STREAM>(reinterpret_cast<V*>(base + (long long)(p * RPO) * di), out);
+    }
   }
 }
 
@@ -135,20 +200,13 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(const Batch b) {
 // transpose_kernel: dims (i, j, k): i is unit-stride in the source, j is unit-stride in the
 // destination, k is the batch dim.  e = {ei, ej, ek}; ss = {1, sj, sk}; ds = {di, 1, dk} (elements).
 // ---------------------------------------------------------------------------------------------
-template <int ES, int VW, int TI, int TJ>
+template <int ES, int VW, int TI, int TJ, bool STREAM>
 __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
   using E = Bytes<ES>;
-  using V = Bytes<ES * VW>;
-  constexpr int TPR = TI / VW;          // lanes per source row segment
-  constexpr int RPP = kThreads / TPR;   // source rows per pass
-  constexpr int NP = TJ / RPP;          // load passes
-  constexpr int TPO = TJ / VW;          // lanes per destination row segment
-  constexpr int RPO = kThreads / TPO;   // destination rows per pass
-  constexpr int NPO = TI / RPO;         // store passes
-  constexpr int PITCH = TI + 1;         // LDS row pitch in elements: +1 keeps column reads <= 2-way conflicted
+  constexpr int PITCH = TI + 1;  // LDS row pitch in elements: +1 keeps column reads <= 2-way conflicted
   static_assert(TI % VW == 0 && TJ % VW == 0, "tile must hold whole vectors");
-  static_assert(kThreads % TPR == 0 && TJ % RPP == 0, "load mapping");
-  static_assert(kThreads % TPO == 0 && TI % RPO == 0, "store mapping");
+  static_assert(kThreads % (TI / VW) == 0 && TJ % (kThreads / (TI / VW)) == 0, "load mapping");
+  static_assert(kThreads % (TJ / VW) == 0 && TI % (kThreads / (TJ / VW)) == 0, "store mapping");
 
   __shared__ E tile[TJ * PITCH];
 
@@ -156,8 +214,18 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
   const DevMove& m = b.m[mi];
   const unsigned int lb = blockIdx.x - b.first_block[mi];
   const unsigned int ti_n = b.t0[mi], tj_n = b.t1[mi];
-  const unsigned int bi = lb % ti_n;
-  const unsigned int rest = lb / ti_n;
+  // Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Give every XCD a
+  // contiguous run of tiles, walked along i first: neighbouring tiles then extend the same source rows
+  // inside ONE L2 / TLB domain instead of being dealt round-robin to all eight (measured on the 1024^3
+  // fp64 permutations: 2.73 -> 2.66 ms strided-read side, 3.02 -> 2.93 ms strided-write side).
+  const unsigned int nb = b.first_block[mi + 1] - b.first_block[mi];
+  unsigned int lt = lb;
+  if (b.p1[mi]) {
+    const unsigned int per = nb >> 3;
+    if (lb < (per << 3)) lt = (lb & 7u) * per + (lb >> 3);
+  }
+  const unsigned int bi = lt % ti_n;
+  const unsigned int rest = lt / ti_n;
   const unsigned int bj = rest % tj_n;
   const long long k = rest / tj_n;
 
@@ -168,40 +236,12 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
   E* __restrict__ dst = reinterpret_cast<E*>(m.dst) + k * dk;
   const int tid = threadIdx.x;
 
-  // ---- global -> registers (all loads issued before the first use) -> LDS, rows along i
-  {
-    const int li = (tid % TPR) * VW;
-    const int lj = tid / TPR;
-    V regs[NP] = {};
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const long long j = j0 + lj + p * RPP;
-      if (i0 + li < ei && j < ej) regs[p] = *reinterpret_cast<const V*>(src + j * sj + i0 + li);
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int jj = lj + p * RPP;
-      E* row = tile + jj * PITCH + li;
-#pragma unroll
-      for (int v = 0; v < VW; ++v) row[v] = Lane<ES, VW>::get(regs[p], v);
-    }
-  }
-  __syncthreads();
-  // ---- LDS -> registers -> global, rows along j
-  {
-    const int lj = (tid % TPO) * VW;
-    const int li = tid / TPO;
-#pragma unroll
-    for (int p = 0; p < NPO; ++p) {
-      const int ii = li + p * RPO;
-      const long long i = i0 + ii;
-      if (i < ei && j0 + lj < ej) {
-        V out;
-#pragma unroll
-        for (int v = 0; v < VW; ++v) Lane<ES, VW>::set(out, v, tile[(lj + v) * PITCH + ii]);
-        *reinterpret_cast<V*>(dst + i * di + j0 + lj) = out;
-      }
-    }
+  // interior tiles skip every bounds test, which lets the compiler batch the 8 loads, the LDS traffic and
+  // the 8 stores of a lane; edge tiles take the guarded copy of the same code
+  if (i0 + TI <= ei && j0 + TJ <= ej) {
+    transposeTile<ES, VW, TI, TJ, STREAM, false>(tile, src, dst, i0, j0, ei, ej, sj, di, tid);
+  } else {
+    transposeTile<ES, VW, TI, TJ, STREAM, true>(tile, src, dst, i0, j0, ei, ej, sj, di, tid);
   }
 }
 
@@ -235,7 +275,8 @@ struct Classified {
   MoveClass cls;
   int variant;  // rows: vector bytes; transpose: elements per vector
   DevMove dm;
-  int p0;
+  int p0, p1;
+  bool stream;
   unsigned int t0, t1;
   unsigned long long blocks;
   i64 elements;
@@ -259,6 +300,7 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
   normalizeMove(m);
   Classified c{};
   c.elements = m.elements();
+  c.stream = (c.elements * es >= kStreamBytes || (tuning && tuning->force_streaming)) && !(tuning && tuning->no_streaming);
   c.dm.src = static_cast<const char*>(bufs[m.src_buf]) + m.src_off * es;
   c.dm.dst = static_cast<char*>(bufs[m.dst_buf]) + m.dst_off * es;
   const bool force_generic = tuning && tuning->force_class == MOVE_GENERIC;
@@ -315,6 +357,7 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
       if (!ok) vw = 1;
     }
     c.variant = vw;
+    c.p1 = 1;  // XCD-contiguous tile walk
     const int ti = (es == 16) ? 32 : 64, tj = ti;
     c.t0 = (unsigned int)((c.dm.e[0] + ti - 1) / ti);
     c.t1 = (unsigned int)((c.dm.e[1] + tj - 1) / tj);
@@ -337,23 +380,24 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
   return c;
 }
 
-void launchBatch(MoveClass cls, int variant, int es, const Batch& b, unsigned int blocks, hipStream_t stream) {
+template <bool STREAM>
+void launchBatchT(MoveClass cls, int variant, int es, const Batch& b, unsigned int blocks, hipStream_t stream) {
   const dim3 grid(blocks), block(kThreads);
   switch (cls) {
     case MOVE_ROWS_VEC:
-      if (variant == 16) rows_kernel<16><<<grid, block, 0, stream>>>(b);
-      else if (variant == 8) rows_kernel<8><<<grid, block, 0, stream>>>(b);
-      else rows_kernel<4><<<grid, block, 0, stream>>>(b);
+      if (variant == 16) rows_kernel<16, STREAM><<<grid, block, 0, stream>>>(b);
+      else if (variant == 8) rows_kernel<8, STREAM><<<grid, block, 0, stream>>>(b);
+      else rows_kernel<4, STREAM><<<grid, block, 0, stream>>>(b);
       break;
     case MOVE_TRANSPOSE:
       if (es == 4) {
-        if (variant == 4) transpose_kernel<4, 4, 64, 64><<<grid, block, 0, stream>>>(b);
-        else transpose_kernel<4, 1, 64, 64><<<grid, block, 0, stream>>>(b);
+        if (variant == 4) transpose_kernel<4, 4, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
+        else transpose_kernel<4, 1, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
       } else if (es == 8) {
-        if (variant == 2) transpose_kernel<8, 2, 64, 64><<<grid, block, 0, stream>>>(b);
-        else transpose_kernel<8, 1, 64, 64><<<grid, block, 0, stream>>>(b);
+        if (variant == 2) transpose_kernel<8, 2, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
+        else transpose_kernel<8, 1, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
       } else {
-        transpose_kernel<16, 1, 32, 32><<<grid, block, 0, stream>>>(b);
+        transpose_kernel<16, 1, 32, 32, STREAM><<<grid, block, 0, stream>>>(b);
       }
       break;
     default:
@@ -363,6 +407,12 @@ void launchBatch(MoveClass cls, int variant, int es, const Batch& b, unsigned in
       break;
   }
   CD_CHECK_HIP(hipGetLastError());
+}
+
+void launchBatch(MoveClass cls, int variant, bool stream_access, int es, const Batch& b, unsigned int blocks,
+                 hipStream_t stream) {
+  if (stream_access) launchBatchT<true>(cls, variant, es, b, blocks, stream);
+  else launchBatchT<false>(cls, variant, es, b, blocks, stream);
 }
 
 }  // namespace
@@ -383,7 +433,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
     Batch b{};
     unsigned long long blocks = 0;
     for (size_t j = i; j < cs.size() && b.n < kMaxBatch; ++j) {
-      if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant) continue;
+      if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant || cs[j].stream != cs[i].stream) continue;
       if (blocks + cs[j].blocks > 0x7fffffffULL) {
         if (b.n == 0) CD_NOT_SUPPORTED("single block move too large for one launch");
         break;
@@ -391,6 +441,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
       b.first_block[b.n] = (unsigned int)blocks;
       b.m[b.n] = cs[j].dm;
       b.p0[b.n] = cs[j].p0;
+      b.p1[b.n] = cs[j].p1;
       b.t0[b.n] = cs[j].t0;
       b.t1[b.n] = cs[j].t1;
       blocks += cs[j].blocks;
@@ -399,7 +450,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
       done[j] = true;
     }
     b.first_block[b.n] = (unsigned int)blocks;
-    launchBatch(cs[i].cls, cs[i].variant, es, b, (unsigned int)blocks, stream);
+    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, es, b, (unsigned int)blocks, stream);
     if (stats) stats->launches[cs[i].cls] += 1;
   }
 }

@@ -19,7 +19,7 @@ def run_move(es, extent, ss, ds, src_len, dst_len, src_off=0, dst_off=0, seed=0,
     dst0 = G.random_payload(dst_len, es, seed + 1)
     exp = dst0.copy()
     orc.move3d_reference(src, exp, extent, ss, ds, src_off, dst_off)
-    for force_generic in (False, True):
+    for force_generic in (0, 1, 2):  # fast path, generic fallback, fast path with streaming access
         d_src, d_dst = G.to_device(src.view(np.uint8)), G.to_device(dst0.view(np.uint8))
         cls = cd.cudecompExtMove3D(d_src.data_ptr() + src_off * es, d_dst.data_ptr() + dst_off * es, es, extent, ss, ds,
                                    force_generic, G.stream_ptr())
@@ -28,7 +28,7 @@ def run_move(es, extent, ss, ds, src_len, dst_len, src_off=0, dst_off=0, seed=0,
         assert np.array_equal(got.view(np.uint8), exp.view(np.uint8)), (es, extent, ss, ds, force_generic, cls)
         if 0 in extent:
             assert cls == -1  # nothing launched
-        elif force_generic:
+        elif force_generic == 1:
             assert cls == 2
         elif expect_cls is not None:
             assert cls == expect_cls, (cls, expect_cls, es, extent, ss, ds)
