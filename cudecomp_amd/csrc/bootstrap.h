@@ -28,6 +28,8 @@ class Bootstrap {
   virtual void allgather(const void* send, void* recv, size_t bytes) = 0;
   // members with the same color form a new communicator, ordered by (key, parent rank)
   virtual std::unique_ptr<Bootstrap> split(int color, int key) = 0;
+  // MPI flavour only: pointer to the underlying MPI_Comm (nullptr for the other providers)
+  virtual void* nativeComm() { return nullptr; }
 
   void barrier();
   void bcast(void* buf, size_t bytes, int root);

@@ -29,20 +29,6 @@ void exportMove(const Move3D& m, cudecompExtMove_t* o) {
   o->reserved = 0;
 }
 
-bool peerTransposeBackend(cudecompTransposeCommBackend_t b) {
-#ifdef CUDECOMP_WITH_MPI
-  return transposeBackendIsPeer(b);
-#else
-  return !transposeBackendIsRccl(b);
-#endif
-}
-bool peerHaloBackend(cudecompHaloCommBackend_t b) {
-#ifdef CUDECOMP_WITH_MPI
-  return haloBackendIsPeer(b);
-#else
-  return !haloBackendIsRccl(b);
-#endif
-}
 
 }  // namespace
 
@@ -61,7 +47,7 @@ cudecompResult_t cudecompExtGetTransposePlan(cudecompHandle_t handle, cudecompGr
         backend_override ? (cudecompTransposeCommBackend_t)backend_override : gd->config.transpose_comm_backend;
     TransportTraits traits;
     traits.pipelined = transposeBackendIsPipelined(backend);
-    traits.symmetric_recv = peerTransposeBackend(backend);
+    traits.symmetric_recv = usesPeerTransport(handle, backend);
     const CommAxis ca = (op == OP_X_TO_Y || op == OP_Y_TO_X) ? COMM_COL : COMM_ROW;
     const cudecompCommInfo& ci = gd->comm(ca);
     const TransposePlan p = buildTransposePlan(gd->shape, handle->rank, (TransposeOp)op, in_halo, out_halo, in_pad,
@@ -111,7 +97,7 @@ cudecompResult_t cudecompExtGetHaloPlan(cudecompHandle_t handle, cudecompGridDes
     const auto backend = backend_override ? (cudecompHaloCommBackend_t)backend_override : gd->config.halo_comm_backend;
     const int32_t zero[3] = {0, 0, 0};
     const HaloPlan p = buildHaloPlan(gd->shape, handle->rank, axis, dim, halo, periods, pad ? pad : zero,
-                                     peerHaloBackend(backend));
+                                     usesPeerTransport(handle, backend));
     std::memset(out, 0, sizeof(*out));
     out->kind = (int32_t)p.kind;
     out->comm_axis = p.comm_axis;

@@ -116,6 +116,17 @@ inline bool haloBackendIsPeer(cudecompHaloCommBackend_t b) {
   return b == CUDECOMP_HALO_COMM_NVSHMEM || b == CUDECOMP_HALO_COMM_NVSHMEM_BLOCKING;
 }
 
+// Which backends travel over the one-sided xGMI peer transport: the NVSHMEM enums always, the MPI enums unless
+// a real MPI communicator is behind the handle (MPI flavour of the library, launched under MPI).
+inline bool usesPeerTransport(cudecompHandle_t h, cudecompTransposeCommBackend_t b) {
+  if (transposeBackendIsRccl(b)) return false;
+  return transposeBackendIsPeer(b) || h->boot->nativeComm() == nullptr;
+}
+inline bool usesPeerTransport(cudecompHandle_t h, cudecompHaloCommBackend_t b) {
+  if (haloBackendIsRccl(b)) return false;
+  return haloBackendIsPeer(b) || h->boot->nativeComm() == nullptr;
+}
+
 // executors
 void runTranspose(cudecompHandle_t handle, cudecompGridDesc_t gd, TransposeOp op, void* input, void* output, void* work,
                   cudecompDataType_t dtype, const int32_t* in_halo, const int32_t* out_halo, const int32_t* in_pad,

@@ -267,8 +267,11 @@ void peerAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan&
 
 void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t, cudecompCommInfo& ci, const TransposePlan& plan,
                       const ExchangeBuffers& b, int es, cudecompTransposeCommBackend_t backend, hipStream_t stream) {
-  if (usesRccl(backend)) rcclAlltoall(h, ci, plan, b, es, stream);
-  else peerAlltoall(h, ci, plan, b, es, stream);
+  if (usesRccl(backend)) return rcclAlltoall(h, ci, plan, b, es, stream);
+#ifdef CUDECOMP_WITH_MPI
+  if (transposeBackendIsMpi(backend) && mpiTransportAvailable(ci)) return mpiAlltoall(h, ci, plan, b, es, stream);
+#endif
+  peerAlltoall(h, ci, plan, b, es, stream);
 }
 
 void alltoallExchangePeers(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
@@ -280,7 +283,11 @@ void alltoallExchangePeers(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCo
   if (!usesRccl(backend)) {
     // The one-sided transport synchronises on the host, so there is nothing to gain from splitting the
     // exchange by peer: run all of it when the schedule reaches the self step, which comes first.
-    if (src_members[0] == me) peerAlltoall(h, ci, plan, b, es, stream);
+    if (src_members[0] != me) return;
+#ifdef CUDECOMP_WITH_MPI
+    if (transposeBackendIsMpi(backend) && mpiTransportAvailable(ci)) return mpiAlltoall(h, ci, plan, b, es, stream);
+#endif
+    peerAlltoall(h, ci, plan, b, es, stream);
     return;
   }
   if (!h->rccl) CD_INTERNAL_ERROR("RCCL communicator was not created for this grid descriptor");
@@ -344,6 +351,9 @@ void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange&
     CD_CHECK_RCCL(ncclGroupEnd());
     return;
   }
+#ifdef CUDECOMP_WITH_MPI
+  if (haloBackendIsMpi(backend) && h->boot->nativeComm()) return mpiHaloExchange(h, x, stream);
+#endif
   if (!h->peer) CD_INTERNAL_ERROR("peer transport was not created for this grid descriptor");
   PeerContext& pc = *h->peer;
   cudecompCommInfo& ci = gd->comm(x.comm_axis);

@@ -65,4 +65,12 @@ struct HaloExchange {
 void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x,
                   cudecompHaloCommBackend_t backend, hipStream_t stream);
 
+#ifdef CUDECOMP_WITH_MPI
+// bootstrap_mpi.cc
+bool mpiTransportAvailable(cudecompCommInfo& ci);
+void mpiAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, const ExchangeBuffers& b, int es,
+                 hipStream_t stream);
+void mpiHaloExchange(cudecompHandle_t h, const HaloExchange& x, hipStream_t stream);
+#endif
+
 }  // namespace cudecomp

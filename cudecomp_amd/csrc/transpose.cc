@@ -8,20 +8,6 @@ namespace cudecomp {
 
 namespace {
 
-bool usesPeerTransport(cudecompTransposeCommBackend_t b) {
-#ifdef CUDECOMP_WITH_MPI
-  return transposeBackendIsPeer(b);
-#else
-  return !transposeBackendIsRccl(b);
-#endif
-}
-bool usesPeerTransport(cudecompHaloCommBackend_t b) {
-#ifdef CUDECOMP_WITH_MPI
-  return haloBackendIsPeer(b);
-#else
-  return !haloBackendIsRccl(b);
-#endif
-}
 
 std::array<int32_t, 3> arr3(const int32_t* p) {
   return p ? std::array<int32_t, 3>{p[0], p[1], p[2]} : std::array<int32_t, 3>{0, 0, 0};
@@ -37,7 +23,7 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
   const auto backend = gd->config.transpose_comm_backend;
   TransportTraits traits;
   traits.pipelined = transposeBackendIsPipelined(backend);
-  traits.symmetric_recv = usesPeerTransport(backend);
+  traits.symmetric_recv = usesPeerTransport(h, backend);
 
   std::array<int32_t, 12> hp;
   {
@@ -111,7 +97,7 @@ void runHalo(cudecompHandle_t h, cudecompGridDesc_t gd, int axis, void* input, v
              const int32_t* halo, const bool* periods, int dim, const int32_t* pad, hipStream_t stream) {
   const int es = elementSize(dtype);
   const auto backend = gd->config.halo_comm_backend;
-  const bool force_packed = usesPeerTransport(backend);
+  const bool force_packed = usesPeerTransport(h, backend);
 
   const auto hh = arr3(halo), pp = arr3(pad);
   std::array<bool, 3> per{false, false, false};
