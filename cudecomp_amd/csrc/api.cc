@@ -233,6 +233,12 @@ void buildCommInfo(cudecompHandle_t h, cudecompGridDesc_t gd) {
   } both[2] = {{&gd->row, COMM_ROW}, {&gd->col, COMM_COL}};
   for (auto& e : both) {
     cudecompCommInfo& ci = *e.info;
+    // barrier-board row of this communicator: reset my cell before the split (a world-wide collective), so
+    // that every member has reset its cell before anybody can use the new communicator
+    ci.barrier_slot = h->next_barrier_slot;
+    h->next_barrier_slot = (h->next_barrier_slot + 1) % 64;
+    ci.barrier_epoch = 0;
+    peerResetBarrierSlot(h, ci.barrier_slot);
     ci.nranks = gd->shape.pdims[e.axis == COMM_ROW ? 1 : 0];
     ci.rank = gd->pidx[e.axis == COMM_ROW ? 1 : 0];
     ci.boot = h->boot->split(gd->pidx[e.axis == COMM_ROW ? 0 : 1], h->rank);

@@ -351,7 +351,23 @@ void autotuneTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecomp
     for (auto backend : backends) {
       gd->config.transpose_comm_backend = backend;
       gd->transpose_plans.clear();
-      for (int i = 0; i < opt->n_warmup_trials; ++i) run_cycle();
+      // A candidate that cannot run here (e.g. a transport that fails to initialise on this system) is
+      // dropped on every rank instead of aborting the sweep.
+      bool failed = false;
+      try {
+        for (int i = 0; i < opt->n_warmup_trials; ++i) run_cycle();
+        CD_CHECK_HIP(hipDeviceSynchronize());
+      } catch (const Error& e) {
+        fprintf(stderr, "%s", e.what());
+        failed = true;
+      }
+      if (h->boot->allreduceOr(failed)) {
+        if (h->rank == 0)
+          printf("CUDECOMP:\tgrid: %d x %d, backend: %s \nCUDECOMP:\t(failed, skipped) \n", pd[0], pd[1],
+                 cudecompTransposeCommBackendToString(backend));
+        (void)hipGetLastError();
+        continue;
+      }
 
       bool skipped = false;
       for (int t = 0; t < n_trials && !skipped; ++t) {

@@ -26,6 +26,8 @@ struct cudecompCommInfo {
   int ngroups = 1, npergroup = 1;           // fast-interconnect groups (hosts) inside the communicator
   std::vector<int> global_ranks;            // member -> rank in the handle's communicator
   std::unique_ptr<cudecomp::Bootstrap> boot;  // control-plane communicator of the members
+  int barrier_slot = -1;                      // row in the shared-memory barrier board (peer transport)
+  uint64_t barrier_epoch = 0;
 };
 
 struct cudecompHandle {
@@ -51,6 +53,7 @@ struct cudecompHandle {
   bool col_major_env_warned = false;
 
   cudecomp::KernelTuning tuning;
+  int next_barrier_slot = 0;  // communicator slots are handed out round-robin, identically on every rank
 
   ~cudecompHandle();
 };

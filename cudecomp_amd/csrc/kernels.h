@@ -29,6 +29,7 @@ struct KernelTuning {
 // Execute `n` independent moves (disjoint destinations) of `es`-byte elements.  bufs[BufId] are the
 // device pointers of the input / output / workspace buffers.  Asynchronous on `stream`.
 void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStream_t stream,
-                 const KernelTuning* tuning = nullptr, KernelStats* stats = nullptr);
+                 const KernelTuning* tuning = nullptr, KernelStats* stats = nullptr,
+                 void* const* dst_base_override = nullptr);  // per-move destination base (remote buffers)
 
 }  // namespace cudecomp

@@ -295,14 +295,14 @@ constexpr int tileI() {
   return ES == 16 ? 32 : 64;
 }
 
-Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelTuning* tuning) {
+Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelTuning* tuning, void* dst_base) {
   Move3D m = in;
   normalizeMove(m);
   Classified c{};
   c.elements = m.elements();
   c.stream = (c.elements * es >= kStreamBytes || (tuning && tuning->force_streaming)) && !(tuning && tuning->no_streaming);
   c.dm.src = static_cast<const char*>(bufs[m.src_buf]) + m.src_off * es;
-  c.dm.dst = static_cast<char*>(bufs[m.dst_buf]) + m.dst_off * es;
+  c.dm.dst = static_cast<char*>(dst_base ? dst_base : bufs[m.dst_buf]) + m.dst_off * es;
   const bool force_generic = tuning && tuning->force_class == MOVE_GENERIC;
 
   if (!force_generic && m.ss[0] <= 1 && m.ds[0] <= 1) {
@@ -418,13 +418,13 @@ void launchBatch(MoveClass cls, int variant, bool stream_access, int es, const B
 }  // namespace
 
 void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStream_t stream,
-                 const KernelTuning* tuning, KernelStats* stats) {
+                 const KernelTuning* tuning, KernelStats* stats, void* const* dst_base_override) {
   if (es != 4 && es != 8 && es != 16) CD_INTERNAL_ERROR("unsupported element size");
   std::vector<Classified> cs;
   cs.reserve(n);
   for (int i = 0; i < n; ++i) {
     if (moves[i].elements() == 0) continue;
-    cs.push_back(classify(moves[i], bufs, es, tuning));
+    cs.push_back(classify(moves[i], bufs, es, tuning, dst_base_override ? dst_base_override[i] : nullptr));
   }
   // moves of one phase are independent, so they may be regrouped by kernel flavour
   std::vector<bool> done(cs.size(), false);

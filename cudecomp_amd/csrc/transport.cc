@@ -4,8 +4,16 @@
 #include <algorithm>
 #include <cstring>
 
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <functional>
+#include <thread>
 
 #include "errors.h"
 
@@ -58,9 +66,11 @@ class PeerContext {
     bool from_library = false;     // allocated by cudecompMalloc
   };
 
-  explicit PeerContext(cudecompHandle_t h) : h_(h) {}
+  // collective over the handle's communicator
+  explicit PeerContext(cudecompHandle_t h) : h_(h) { openBoard(); }
 
   ~PeerContext() {
+    if (board_) ::munmap(board_, board_bytes_);
     for (auto& kv : regions_) closePeers(kv.second);
     for (hipStream_t s : copy_streams_) (void)hipStreamDestroy(s);
   }
@@ -139,6 +149,38 @@ class PeerContext {
 
   bool anyUnregistered(const void* local) { return find(local) == nullptr; }
 
+  // ---- host barrier among the members of a row / column communicator -------------------------------
+  // Hot path of the host-ordered exchanges: a shared-memory epoch board (one cache line per rank and
+  // communicator slot) when all members share this host, the bootstrap's all-gather otherwise.
+  static constexpr int kSlots = 256;
+
+  void barrier(cudecompCommInfo& ci) {
+    if (!board_ || ci.ngroups != 1 || ci.barrier_slot < 0) {
+      ci.boot->barrier();
+      return;
+    }
+    const uint64_t epoch = ++ci.barrier_epoch;
+    cell(ci.barrier_slot, h_->rank).store(epoch, std::memory_order_release);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    for (int m = 0; m < ci.nranks; ++m) {
+      auto& c = cell(ci.barrier_slot, ci.global_ranks[m]);
+      int spins = 0;
+      while (c.load(std::memory_order_acquire) < epoch) {
+        if (++spins > 2000) {
+          std::this_thread::yield();
+          if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() > deadline)
+            CD_PEER_ERROR("timed out in the shared-memory barrier (a peer rank died?)");
+        }
+      }
+    }
+  }
+
+  // a communicator slot is (re)initialised by its members BEFORE the collective that creates the communicator
+  void resetSlot(int slot) {
+    if (board_ && slot >= 0) cell(slot, h_->rank).store(0, std::memory_order_release);
+  }
+  bool hasBoard() const { return board_ != nullptr; }
+
   hipStream_t copyStream(int i) {
     while ((int)copy_streams_.size() <= i) {
       hipStream_t s;
@@ -154,10 +196,53 @@ class PeerContext {
       if (p != h_->rank && r.peer_base[p]) (void)hipIpcCloseMemHandle(r.peer_base[p]);
   }
 
+  std::atomic<uint64_t>& cell(int slot, int rank) {
+    return *reinterpret_cast<std::atomic<uint64_t>*>(board_ + ((size_t)slot * h_->nranks + rank) * 64);
+  }
+
+  void openBoard() {
+    // every host gets its own segment; its name is agreed through the bootstrap, the creator unlinks it as
+    // soon as all local ranks have mapped it, so nothing is left behind even if a rank crashes later
+    board_bytes_ = (size_t)kSlots * h_->nranks * 64;
+    char name[128] = {0};
+    if (h_->local_rank == 0)
+      snprintf(name, sizeof(name), "/cudecomp_%d_%llx", (int)::getpid(),
+               (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+    std::vector<char> all((size_t)128 * h_->nranks);
+    h_->boot->allgather(name, all.data(), 128);
+    int creator = -1;
+    for (int r = 0; r < h_->nranks; ++r)
+      if (h_->hostnames[r] == h_->hostnames[h_->rank] && h_->rank_to_local_rank[r] == 0) creator = r;
+    const char* shm_name = all.data() + (size_t)128 * creator;
+    int fd = -1;
+    if (h_->local_rank == 0) {
+      fd = ::shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd >= 0 && ::ftruncate(fd, (off_t)board_bytes_) != 0) {
+        ::close(fd);
+        fd = -1;
+      }
+    }
+    h_->boot->barrier();
+    if (h_->local_rank != 0) fd = ::shm_open(shm_name, O_RDWR, 0600);
+    void* p = (fd >= 0) ? ::mmap(nullptr, board_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+    if (fd >= 0) ::close(fd);
+    const bool ok = (p != MAP_FAILED);
+    const bool all_ok = !h_->boot->allreduceOr(!ok);  // also: everybody has mapped it
+    if (h_->local_rank == 0) ::shm_unlink(shm_name);
+    if (ok && all_ok) board_ = static_cast<char*>(p);
+    else if (ok) ::munmap(p, board_bytes_);  // fall back to bootstrap barriers everywhere
+  }
+
   cudecompHandle_t h_;
   std::map<char*, Region> regions_;
   std::vector<hipStream_t> copy_streams_;
+  char* board_ = nullptr;
+  size_t board_bytes_ = 0;
 };
+
+void peerResetBarrierSlot(cudecompHandle_t h, int slot) {
+  if (h->peer) h->peer->resetSlot(slot);
+}
 
 void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
   if (h->nranks == 1) return;  // every communicator has one member: nothing ever travels
@@ -252,7 +337,7 @@ void peerAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan&
     const int d = p.schedule_dst[j];
     remote[d] = pc.translate(b.recv, ci.global_ranks[d]) + p.remote_recv_off[d] * es;
   }
-  ci.boot->barrier();
+  pc.barrier(ci);
   for (int j = 0; j < ci.nranks; ++j) {
     const int d = p.schedule_dst[j];
     if (p.send_cnt[d] == 0) continue;
@@ -260,10 +345,53 @@ void peerAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan&
                                 hipMemcpyDeviceToDevice, pc.copyStream(j)));
   }
   for (int j = 0; j < ci.nranks; ++j) CD_CHECK_HIP(hipStreamSynchronize(pc.copyStream(j)));
-  ci.boot->barrier();
+  pc.barrier(ci);
 }
 
 }  // namespace
+
+// "SM"-style exchange (NVSHMEM_SM enum): the pack kernels write each chunk straight into the receiver's
+// IPC-mapped receive area over xGMI -- one launch feeds all links at once, and the send area, the copy
+// engines and one full HBM pass disappear.  The reference's counterpart is the NVSHMEM block-put kernel
+// (include/internal/cudecomp_kernels.cuh:86-122); here it is the ordinary move kernel with a remote
+// destination.  Host-ordered like peerAlltoall.
+void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& p, void* const bufs[3], int es,
+                     hipStream_t stream) {
+  if (!h->peer) CD_INTERNAL_ERROR("peer transport was not created for this grid descriptor");
+  PeerContext& pc = *h->peer;
+  char* recv_local = static_cast<char*>(bufs[p.recv_buf]) + p.recv_base * es;
+  CD_CHECK_HIP(hipStreamSynchronize(stream));
+  std::vector<char*> remote(ci.nranks);
+  for (int d = 0; d < ci.nranks; ++d) remote[d] = pc.translate(recv_local, ci.global_ranks[d]);
+  pc.barrier(ci);  // every member's receive area is free again
+
+  std::vector<Move3D> moves;
+  std::vector<void*> dst_base;
+  if (!p.pack.empty()) {
+    for (const Move3D& m : p.pack) {
+      Move3D r = m;
+      r.dst_off = p.remote_recv_off[m.peer];
+      moves.push_back(r);
+      dst_base.push_back(remote[m.peer]);
+    }
+  } else {  // chunks already sit packed in the send buffer (skip-pack plans): plain copies to the peers
+    for (int j = 0; j < ci.nranks; ++j) {
+      const int d = p.schedule_dst[j];
+      Move3D r;
+      r.src_buf = p.send_buf;
+      r.src_off = p.send_base + p.send_off[d];
+      r.dst_off = p.remote_recv_off[d];
+      r.extent[0] = p.send_cnt[d];
+      r.ss[0] = r.ds[0] = 1;
+      r.peer = d;
+      moves.push_back(r);
+      dst_base.push_back(remote[d]);
+    }
+  }
+  launchMoves(moves.data(), (int)moves.size(), bufs, es, stream, &h->tuning, nullptr, dst_base.data());
+  CD_CHECK_HIP(hipStreamSynchronize(stream));
+  pc.barrier(ci);  // every chunk has landed everywhere
+}
 
 void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t, cudecompCommInfo& ci, const TransposePlan& plan,
                       const ExchangeBuffers& b, int es, cudecompTransposeCommBackend_t backend, hipStream_t stream) {
@@ -363,13 +491,13 @@ void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange&
   if (pc.anyUnregistered(x.recv)) (void)pc.translate(x.recv, h->rank);
   for (int i = 0; i < 2; ++i)
     if (x.neighbor[i] != -1) remote[i] = pc.translate(x.recv, x.neighbor[i]) + x.remote_off[i];
-  ci.boot->barrier();
+  pc.barrier(ci);
   for (int i = 0; i < 2; ++i)
     if (x.neighbor[i] != -1)
       CD_CHECK_HIP(hipMemcpyAsync(remote[i], x.send + x.send_off[i], (size_t)x.bytes, hipMemcpyDeviceToDevice,
                                   pc.copyStream(i)));
   for (int i = 0; i < 2; ++i) CD_CHECK_HIP(hipStreamSynchronize(pc.copyStream(i)));
-  ci.boot->barrier();
+  pc.barrier(ci);
 }
 
 }  // namespace cudecomp

@@ -27,6 +27,8 @@ MPI_Comm commFromFortran(MPI_Fint f);
 // collective: create the RCCL communicator / the peer registry if they will be needed
 void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer);
 
+void peerResetBarrierSlot(cudecompHandle_t h, int slot);
+
 void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes);  // collective
 // same, without a grid descriptor: peer_capable = map the buffer into the other ranks for one-sided writes
 void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable);
@@ -43,6 +45,10 @@ struct ExchangeBuffers {
 // as the reference's MPI backends do).
 void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
                       const ExchangeBuffers& b, int es, cudecompTransposeCommBackend_t backend, hipStream_t stream);
+
+// Fused pack + put (NVSHMEM_SM enum): runs the plan's pack moves with the peers' receive areas as destinations.
+void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, void* const bufs[3], int es,
+                     hipStream_t stream);
 
 // Per-peer variant used by the pipelined backends: exchange with the given members only.  Waits for
 // pack_done[dst] before sending to dst and makes `stream` wait for the arrival of each chunk.

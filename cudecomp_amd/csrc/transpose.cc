@@ -60,6 +60,12 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
   xb.send = static_cast<char*>(bufs[plan.send_buf]) + plan.send_base * es;
   xb.recv = static_cast<char*>(bufs[plan.recv_buf]) + plan.recv_base * es;
 
+  if (backend == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_SM) {
+    // compute-unit driven: pack straight into the peers' receive areas
+    peerPutExchange(h, ci, plan, bufs, es, stream);
+    launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
+    return;
+  }
   if (!traits.pipelined) {
     launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
     alltoallExchange(h, gd, ci, plan, xb, es, backend, stream);

@@ -76,8 +76,10 @@ def test_cycle_multi_rank_peer_transport(n):
             continue
         for ac, work, backend in ((K.DEFAULT_AC, "malloc", cd.TRANSPOSE_COMM_MPI_P2P),
                                   (K.ALL_AC, "torch", cd.TRANSPOSE_COMM_MPI_A2A),
-                                  (K.ALL_AC, "malloc", cd.TRANSPOSE_COMM_NVSHMEM)):
-            jobs.append({"fn": "transpose_chain", "id": "P%dx%d_%s_%s" % (pdims[0], pdims[1], ac, work),
+                                  (K.ALL_AC, "malloc", cd.TRANSPOSE_COMM_NVSHMEM),
+                                  (K.ALL_AC, "malloc", cd.TRANSPOSE_COMM_NVSHMEM_SM),
+                                  (K.DEFAULT_AC, "torch", cd.TRANSPOSE_COMM_NVSHMEM_SM)):
+            jobs.append({"fn": "transpose_chain", "id": "P%dx%d_%s_%s_b%d" % (pdims[0], pdims[1], ac, work, backend),
                          "args": {"gdims": (32, 24, 40), "pdims": pdims, "ac": ac, "kind": 1, "work_alloc": work,
                                   "transpose_backend": backend}})
     for failures in run_ranks(n, "tests.gpu_bodies", "many", {"jobs": jobs}, timeout=600):
