@@ -57,6 +57,21 @@ def measured_traffic(layout):
         return None
 
 
+class c_stdout_to_stderr:
+    """Route C-level stdout (the library's autotune log) to stderr for the duration of the block."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def cpu_baseline(sample, layout):
     """Oracle timed on this host: one X->Y->Z->Y->X cycle of a sample^3 fp64 array, 1x1 grid, same layout."""
     import numpy as np
@@ -104,23 +119,37 @@ def main():
     n = args.size
     ac = (1, 1, 1) if args.layout == "contiguous" else (0, 0, 0)
     backends = {"nccl": cd.TRANSPOSE_COMM_NCCL, "nccl_pl": cd.TRANSPOSE_COMM_NCCL_PL,
-                "peer": cd.TRANSPOSE_COMM_NVSHMEM, "peer_pl": cd.TRANSPOSE_COMM_NVSHMEM_PL}
-    choice = args.backend if args.backend != "auto" else "nccl"
-    pdims = tuple(args.pdims) if args.pdims else (1, world)
+                "peer": cd.TRANSPOSE_COMM_NVSHMEM, "peer_pl": cd.TRANSPOSE_COMM_NVSHMEM_PL,
+                "peer_sm": cd.TRANSPOSE_COMM_NVSHMEM_SM, "mpi": cd.TRANSPOSE_COMM_MPI_P2P}
+    names = {v: k for k, v in backends.items()}
 
     h = cd.cudecompInit()
-    gd, used = None, None
-    for cand in ([choice] if args.backend != "auto" else ["nccl", "peer"]):
-        try:
-            cfg = cd.make_config((n, n, n), pdims, axis_contiguous=ac, transpose_backend=backends[cand])
+    autotuned = None
+    if world == 1:
+        pdims = (1, 1)
+        cfg = cd.make_config((n, n, n), pdims, axis_contiguous=ac,
+                             transpose_backend=backends.get(args.backend, cd.TRANSPOSE_COMM_NCCL))
+        gd = cd.cudecompGridDescCreate(h, cfg)
+    else:
+        # BASELINE config 3: "autotuned pgrid".  The library's own autotuner (cudecompGridDescCreate with options)
+        # times every process grid x transport through the public transposes and keeps the fastest; a transport that
+        # cannot run on this system is dropped by the sweep.  --pdims / --backend pin either choice.
+        cfg = cd.make_config((n, n, n), tuple(args.pdims) if args.pdims else (0, 0), axis_contiguous=ac,
+                             transpose_backend=backends.get(args.backend, cd.TRANSPOSE_COMM_NCCL))
+        opt = cd.cudecompGridDescAutotuneOptionsSetDefaults()
+        opt.dtype = cd.DOUBLE
+        opt.n_warmup_trials, opt.n_trials = 2, 3
+        opt.autotune_transpose_backend = (args.backend == "auto")
+        for i in range(4):
+            opt.transpose_use_inplace_buffers[i] = bool(args.inplace)
+        if args.backend == "auto" or not args.pdims:
+            with c_stdout_to_stderr():  # the sweep logs "CUDECOMP: ..." lines on stdout; keep ours a single JSON line
+                gd = cd.cudecompGridDescCreate(h, cfg, opt)
+            autotuned = {"pdims": args.pdims is None, "backend": args.backend == "auto"}
+        else:
             gd = cd.cudecompGridDescCreate(h, cfg)
-            used = cand
-            break
-        except cd.CudecompError as e:
-            if rank == 0:
-                print("bench: backend %s unavailable (%s)" % (cand, e), file=sys.stderr)
-    if gd is None:
-        raise SystemExit("no usable transport")
+        pdims = (cfg.pdims[0], cfg.pdims[1])
+    used = names.get(cfg.transpose_comm_backend, cd.cudecompTransposeCommBackendToString(cfg.transpose_comm_backend))
 
     es = 8
     pinfo = [cd.cudecompGetPencilInfo(h, gd, ax) for ax in range(3)]
@@ -174,7 +203,21 @@ def main():
         t = torch.tensor([wall, dev_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
-    ok = int(a[:pinfo[0].size].sum()) == checksum0  # an even number of cycles... every cycle returns the input
+    ok = int(a[:pinfo[0].size].sum()) == checksum0  # every cycle returns the X pencil to `a`
+
+    # bytes this rank pushes across the half/half cut of the node per cycle (for the bisection fraction)
+    cut = 0
+    if world > 1:
+        for op in cd.OPS:
+            p = cd.cudecompExtGetTransposePlan(h, gd, op, inplace=args.inplace)
+            if p.exchange:
+                for d in range(p.nranks):
+                    peer = p.member_global_rank[d]
+                    if (peer < world // 2) != (rank < world // 2):
+                        cut += p.send_cnt[d] * es
+        t = torch.tensor([cut], dtype=torch.int64)
+        dist.all_reduce(t)
+        cut = int(t[0])
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -202,10 +245,17 @@ def main():
                                    % (n, pdims[0], pdims[1],
                                       "all-axis-contiguous" if args.layout == "contiguous" else "default (X fastest)",
                                       "in-place" if args.inplace else "out-of-place"),
-                       "pdims": list(pdims), "transport": used, "per_op_ms": [round(x, 4) for x in op_ms],
-                       "round_trip_checksum_ok": bool(ok)},
+                       "pdims": list(pdims), "transport": used, "autotuned": autotuned,
+                       "per_op_ms": [round(x, 4) for x in op_ms], "round_trip_checksum_ok": bool(ok)},
             "roofline": roof,
         }
+        if world > 1:
+            # nominal xGMI link: 153.6 GB/s counting both directions (task statement); (N/2)^2 links cross the cut
+            link = 153.6
+            bis = (world // 2) ** 2 * link
+            out["xgmi"] = {"cut_bytes_per_cycle": cut, "cut_GBps": round(cut / (ms_per_step * 1e-3) / 1e9, 1),
+                           "bisection_GBps_nominal": bis,
+                           "frac_of_bisection": round(cut / (ms_per_step * 1e-3) / 1e9 / bis, 4)}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.layout)
         print(json.dumps(out))

@@ -437,8 +437,11 @@ cudecompResult_t cudecompGridDescCreateVersioned(cudecompHandle_t handle, cudeco
                      (!tune_hb && haloBackendIsRccl(cfg.halo_comm_backend));
     bool need_peer = (!tune_tb && !transposeBackendIsRccl(cfg.transpose_comm_backend)) ||
                      (!tune_hb && !haloBackendIsRccl(cfg.halo_comm_backend));
-    for (auto b : t_cand) (transposeBackendIsRccl(b) ? need_rccl : need_peer) = true;
-    for (auto b : h_cand) (haloBackendIsRccl(b) ? need_rccl : need_peer) = true;
+    // (RCCL for autotune CANDIDATES is set up inside the sweep, which tolerates its absence)
+    for (auto b : t_cand)
+      if (!transposeBackendIsRccl(b)) need_peer = true;
+    for (auto b : h_cand)
+      if (!haloBackendIsRccl(b)) need_peer = true;
     prepareTransports(handle, need_rccl, need_peer);
 
     if (have_opt) {

@@ -266,6 +266,24 @@ void autotuneTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecomp
                    : std::vector<cudecompTransposeCommBackend_t>{gd->config.transpose_comm_backend};
   bool any_rccl = false, any_peer = false;
   for (auto b : backends) (transposeBackendIsRccl(b) ? any_rccl : any_peer) = true;
+  if (any_rccl && tune_backend) {
+    // RCCL may be unusable in this job (e.g. several ranks on one device): drop its candidates, keep going
+    bool ok = true;
+    try {
+      prepareTransports(h, true, false);
+    } catch (const Error& e) {
+      fprintf(stderr, "%s", e.what());
+      ok = false;
+    }
+    if (h->boot->allreduceOr(!ok)) {
+      h->rccl.reset();
+      (void)hipGetLastError();
+      backends.erase(std::remove_if(backends.begin(), backends.end(), transposeBackendIsRccl), backends.end());
+      if (h->rank == 0) printf("CUDECOMP:WARN: RCCL communicator could not be created; skipping NCCL backends.\n");
+      if (backends.empty()) CD_NOT_SUPPORTED("no usable transpose backend on this system");
+      any_rccl = false;
+    }
+  }
   prepareTransports(h, any_rccl, any_peer);
 
   std::vector<std::array<int32_t, 2>> grids;
@@ -470,6 +488,23 @@ void autotuneHalo(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecompGridD
       tune_backend ? haloBackendCandidates(opt) : std::vector<cudecompHaloCommBackend_t>{gd->config.halo_comm_backend};
   bool any_rccl = false, any_peer = false;
   for (auto b : backends) (haloBackendIsRccl(b) ? any_rccl : any_peer) = true;
+  if (any_rccl && tune_backend) {
+    bool ok = true;
+    try {
+      prepareTransports(h, true, false);
+    } catch (const Error& e) {
+      fprintf(stderr, "%s", e.what());
+      ok = false;
+    }
+    if (h->boot->allreduceOr(!ok)) {
+      h->rccl.reset();
+      (void)hipGetLastError();
+      backends.erase(std::remove_if(backends.begin(), backends.end(), haloBackendIsRccl), backends.end());
+      if (h->rank == 0) printf("CUDECOMP:WARN: RCCL communicator could not be created; skipping NCCL backends.\n");
+      if (backends.empty()) CD_NOT_SUPPORTED("no usable halo backend on this system");
+      any_rccl = false;
+    }
+  }
   prepareTransports(h, any_rccl, any_peer);
 
   std::vector<std::array<int32_t, 2>> grids;
