@@ -25,7 +25,7 @@ def free_port():
     return p
 
 
-def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None):
+def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_rank_env=None):
     port_a, port_b = free_port(), free_port()
     outdir = tempfile.mkdtemp(prefix="cudecomp_mp_")
     procs = []
@@ -37,6 +37,8 @@ def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None):
                     "PYTHONPATH": ROOT + os.pathsep + env.get("PYTHONPATH", "")})
         if extra_env:
             env.update(extra_env)
+        if per_rank_env:
+            env.update(per_rank_env[r])
         out = os.path.join(outdir, "rank%d.json" % r)
         cmd = [sys.executable, os.path.abspath(__file__), module, func, json.dumps(args or {}), out]
         procs.append((subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), out))

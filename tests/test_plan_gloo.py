@@ -36,3 +36,15 @@ def test_world34_plans(nranks, pdims, ro):
                 "backends": BACKENDS}
         for failures in run_ranks(nranks, "tests.bodies", "plan_transpose_gloo", args):
             assert failures == []
+
+
+@pytest.mark.parametrize("nranks,pdims,hosts", [(3, (3, 1), "abc"), (6, (6, 1), "aabbcc"), (6, (1, 6), "aaabbb")])
+def test_synthetic_host_groups(nranks, pdims, hosts):
+    # reference tests/ctest/transpose_tests.cc:239-273 (SyntheticInterGroup*): ranks spread over several "hosts"
+    # exercise the two-level (intra-group then inter-group) ring schedule of non-power-of-two communicators
+    args = {"gdims": (13, 12, 14), "pdims": pdims, "kind": 0,
+            "backends": [cd.TRANSPOSE_COMM_NCCL, cd.TRANSPOSE_COMM_NCCL_PL],
+            "halos": [K.IN_HALO, K.OUT_HALO, K.IN_HALO], "pads": [K.IN_PAD, K.OUT_PAD, K.IN_PAD]}
+    env = [{"CUDECOMP_HOSTNAME_OVERRIDE": "node-" + h} for h in hosts]
+    for failures in run_ranks(nranks, "tests.bodies", "plan_transpose_gloo", args, per_rank_env=env):
+        assert failures == []
