@@ -230,3 +230,26 @@ def test_autotune_candidate_filters(handle, monkeypatch):
     monkeypatch.delenv("CUDECOMP_AUTOTUNE_P_ROW_RANGE")
     opt.grid_mode = 7
     assert create(cfg0, opt) in (cd.RESULT_INVALID_USAGE, cd.RESULT_CUDA_ERROR)
+
+
+def test_empty_pencils_and_wide_halos_are_rejected_by_the_planner(handle):
+    # reference include/internal/transpose.h:257-259, halo.h:57-59 (NOT_SUPPORTED) and halo.h:120-144 (INVALID_USAGE);
+    # the planner runs before any device work, so this needs no GPU
+    L = cd.lib()
+    i3 = (C.c_int32 * 3)
+    # one rank can never have empty pencils; a zero-extent grid is the degenerate way to get one
+    gd = cd.cudecompGridDescCreate(handle, cd.make_config((0, 4, 4), (1, 1)))
+    plan = cd.ExtTransposePlan()
+    rc = L.cudecompExtGetTransposePlan(handle, gd, 0, None, None, None, None, False, 0, C.byref(plan))
+    assert rc == cd.RESULT_NOT_SUPPORTED
+    hp = cd.ExtHaloPlan()
+    rc = L.cudecompExtGetHaloPlan(handle, gd, 1, i3(1, 1, 1), None, 2, None, 0, C.byref(hp))  # Y pencils split X
+    assert rc == cd.RESULT_NOT_SUPPORTED
+    assert L.cudecompTransposeXToY(handle, gd, 8, 8, 8, cd.FLOAT, None, None, None, None, None) == cd.RESULT_NOT_SUPPORTED
+    cd.cudecompGridDescDestroy(handle, gd)
+    # negative halo extents reach the planner through the transposes too
+    gd = cd.cudecompGridDescCreate(handle, cd.make_config((8, 8, 8), (1, 1)))
+    assert L.cudecompTransposeXToY(handle, gd, 8, 16, 8, cd.FLOAT, i3(-1, 0, 0), None, None, None, None) == cd.RESULT_INVALID_USAGE
+    # single rank, in place, identical layout: nothing to do, returns before touching the device
+    assert L.cudecompTransposeXToY(handle, gd, 8, 8, 8, cd.FLOAT, None, None, None, None, None) == cd.RESULT_SUCCESS
+    cd.cudecompGridDescDestroy(handle, gd)

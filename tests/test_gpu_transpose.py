@@ -122,3 +122,37 @@ def test_round_trip_and_checksum_at_benchmark_size():
     assert torch.equal(b[y + n * (z + n * x)], keep[x + n * (y + n * z)])
     cd.cudecompFree(h, gd, work)
     cd.cudecompGridDescDestroy(h, gd)
+
+
+def test_more_than_2_31_elements_per_pencil():
+    """Maximum-size edge: 2048 x 1024 x 1056 fp32 = 2.2e9 elements (> 2^31) in one pencil; 64-bit indexing in
+    every kernel flavour.  Properties only: the cycle returns the input bit for bit and each hop preserves the
+    multiset (sum of the raw 32-bit words)."""
+    from tests import gpu_util as G
+    gdims = (2048, 1024, 1056)
+    nel = gdims[0] * gdims[1] * gdims[2]
+    assert nel > 2**31
+    h = B._handle(0)
+    for ac in ((1, 1, 1), (0, 0, 0)):
+        gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims, (1, 1), axis_contiguous=ac))
+        g = torch.Generator(device="cuda")
+        g.manual_seed(7)
+        a = torch.randint(-2**31, 2**31 - 1, (nel,), dtype=torch.int32, device="cuda", generator=g)
+        ref_sum = int(a.sum(dtype=torch.int64))
+        keep_head, keep_tail = a[:4096].clone(), a[-4096:].clone()
+        probe = torch.randint(0, nel, (8192,), device="cuda", generator=g)
+        keep_probe = a[probe].clone()
+        b = torch.empty_like(a)
+        work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * 4)
+        cur, nxt = a, b
+        for op in cd.OPS:
+            cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.FLOAT, stream=G.stream_ptr())
+            torch.cuda.synchronize()
+            assert int(nxt.sum(dtype=torch.int64)) == ref_sum, (ac, op)
+            cur, nxt = nxt, cur
+        assert torch.equal(cur[:4096], keep_head) and torch.equal(cur[-4096:], keep_tail)
+        assert torch.equal(cur[probe], keep_probe)
+        cd.cudecompFree(h, gd, work)
+        cd.cudecompGridDescDestroy(h, gd)
+        del a, b, cur, nxt
+        torch.cuda.empty_cache()
