@@ -123,6 +123,8 @@ def main():
                 "peer_sm": cd.TRANSPOSE_COMM_NVSHMEM_SM, "mpi": cd.TRANSPOSE_COMM_MPI_P2P}
     names = {v: k for k, v in backends.items()}
 
+    if world > 1:
+        os.environ["CUDECOMP_ENABLE_PERFORMANCE_REPORT"] = "1"  # per-op local / exchange split, reported below
     h = cd.cudecompInit()
     autotuned = None
     if world == 1:
@@ -205,6 +207,18 @@ def main():
         wall, dev_ms = float(t[0]), float(t[1])
     ok = int(a[:pinfo[0].size].sum()) == checksum0  # every cycle returns the X pencil to `a`
 
+    # where the time goes: per-op averages of [pack | exchange | unpack] recorded by the library (max over ranks)
+    split = None
+    if world > 1:
+        rows = []
+        for op in cd.OPS:
+            t = cd.cudecompExtGetTransposeTimings(h, gd, op)
+            rows.append([t["pack_ms"], t["exchange_ms"], t["unpack_ms"]])
+        tt = torch.tensor(rows, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        split = {op: {"pack_ms": round(float(tt[i][0]), 4), "exchange_ms": round(float(tt[i][1]), 4),
+                      "unpack_ms": round(float(tt[i][2]), 4)} for i, op in enumerate(cd.OPS)}
+
     # bytes this rank pushes across the half/half cut of the node per cycle (for the bisection fraction)
     cut = 0
     if world > 1:
@@ -246,7 +260,8 @@ def main():
                                       "all-axis-contiguous" if args.layout == "contiguous" else "default (X fastest)",
                                       "in-place" if args.inplace else "out-of-place"),
                        "pdims": list(pdims), "transport": used, "autotuned": autotuned,
-                       "per_op_ms": [round(x, 4) for x in op_ms], "round_trip_checksum_ok": bool(ok)},
+                       "per_op_ms": [round(x, 4) for x in op_ms], "per_op_split": split,
+                       "round_trip_checksum_ok": bool(ok)},
             "roofline": roof,
         }
         if world > 1:
@@ -261,7 +276,8 @@ def main():
         print(json.dumps(out))
 
     cd.cudecompFree(h, gd, work)
-    cd.cudecompGridDescDestroy(h, gd)
+    with c_stdout_to_stderr():  # the library prints its performance summary here when enabled
+        cd.cudecompGridDescDestroy(h, gd)
     cd.cudecompFinalize(h)
     if world > 1:
         dist.destroy_process_group()

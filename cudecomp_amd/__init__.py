@@ -103,7 +103,13 @@ API_SYMBOLS = [
     "cudecompTransposeYToZ", "cudecompTransposeZToY", "cudecompTransposeYToX", "cudecompUpdateHalosX",
     "cudecompUpdateHalosY", "cudecompUpdateHalosZ",
 ]
-EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecompExtMove3D"]
+EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecompExtMove3D",
+               "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe"]
+
+
+class ExtTransposeTimings(C.Structure):
+    _fields_ = [("calls", C.c_int64), ("samples", C.c_int64), ("total_ms", C.c_double), ("pack_ms", C.c_double),
+                ("exchange_ms", C.c_double), ("unpack_ms", C.c_double), ("pencil_bytes", C.c_int64)]
 
 
 class CudecompError(RuntimeError):
@@ -161,6 +167,8 @@ def lib():
                                                   C.POINTER(ExtTransposePlan)]
         L.cudecompExtGetHaloPlan.argtypes = [vp, vp, i32, pi32, C.POINTER(C.c_bool), i32, pi32, i32,
                                              C.POINTER(ExtHaloPlan)]
+        L.cudecompExtGetTransposeTimings.argtypes = [vp, vp, i32, C.POINTER(ExtTransposeTimings)]
+        L.cudecompExtPeerProbe.argtypes = [vp, vp, C.c_size_t, pi32]
         L.cudecompExtMove3D.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32, pi32, vp]
         _lib = L
     return _lib
@@ -304,6 +312,18 @@ def cudecompExtGetHaloPlan(handle, gd, axis, halo_extents, halo_periods, dim, pa
     _check(lib().cudecompExtGetHaloPlan(handle, gd, axis, _i3(halo_extents), _b3(halo_periods), dim, _i3(padding),
                                         backend_override, C.byref(p)), "cudecompExtGetHaloPlan")
     return p
+
+
+def cudecompExtGetTransposeTimings(handle, gd, op):
+    t = ExtTransposeTimings()
+    _check(lib().cudecompExtGetTransposeTimings(handle, gd, OPS.index(op), C.byref(t)), "cudecompExtGetTransposeTimings")
+    return {k: getattr(t, k) for k, _ in ExtTransposeTimings._fields_}
+
+
+def cudecompExtPeerProbe(handle, buffer, nbytes):
+    bad = C.c_int32(-1)
+    _check(lib().cudecompExtPeerProbe(handle, buffer, nbytes, C.byref(bad)), "cudecompExtPeerProbe")
+    return bad.value
 
 
 def cudecompExtMove3D(src, dst, es, extent, ss, ds, force_generic=False, stream=None):

@@ -275,6 +275,10 @@ cudecompHandle::~cudecompHandle() {
 }
 
 cudecompGridDesc::~cudecompGridDesc() {
+  for (auto& ring : perf)
+    for (auto& s : ring)
+      for (hipEvent_t e : s.ev)
+        if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
 }
 
@@ -462,6 +466,7 @@ cudecompResult_t cudecompGridDescCreateVersioned(cudecompHandle_t handle, cudeco
     buildCommInfo(handle, gd);
     gd->transpose_plans.clear();
     gd->halo_plans.clear();
+    perfReset(gd);  // autotuning trials are not part of the user's performance report
 
     *grid_desc_out = gd;
     copyConfigOut(config, config_struct_size, config_version, gd);
@@ -474,6 +479,7 @@ cudecompResult_t cudecompGridDescDestroy(cudecompHandle_t handle, cudecompGridDe
   try {
     checkHandle(handle);
     checkGridDesc(handle, grid_desc);
+    perfReport(handle, grid_desc);
     grid_desc->initialized = false;
     delete grid_desc;
   }

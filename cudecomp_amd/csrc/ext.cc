@@ -5,6 +5,7 @@
 #include "cudecomp_ext.h"
 #include "errors.h"
 #include "internal.h"
+#include "transport.h"
 
 using namespace cudecomp;
 
@@ -112,6 +113,41 @@ cudecompResult_t cudecompExtGetHaloPlan(cudecompHandle_t handle, cudecompGridDes
     out->n_post = (int32_t)p.post.size();
     for (size_t i = 0; i < p.pre.size(); ++i) exportMove(p.pre[i], &out->pre[i]);
     for (size_t i = 0; i < p.post.size(); ++i) exportMove(p.post[i], &out->post[i]);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtGetTransposeTimings(cudecompHandle_t handle, cudecompGridDesc_t gd, int32_t op,
+                                                cudecompExtTransposeTimings_t* out) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    if (!gd || !gd->initialized || gd->handle != handle) CD_INVALID_USAGE("invalid grid descriptor");
+    if (!out || op < 0 || op > 3) CD_INVALID_USAGE("bad argument");
+    const TransposeTimings t = perfCollect(gd, op);
+    out->calls = t.calls;
+    out->samples = t.samples;
+    out->total_ms = t.total_ms;
+    out->pack_ms = t.pack_ms;
+    out->exchange_ms = t.exchange_ms;
+    out->unpack_ms = t.unpack_ms;
+    out->pencil_bytes = t.pencil_bytes;
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtPeerProbe(cudecompHandle_t handle, void* buffer, size_t bytes, int32_t* mismatches) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    if (!buffer || !mismatches) CD_INVALID_USAGE("null argument");
+    *mismatches = peerProbe(handle, buffer, bytes);
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {

@@ -1,5 +1,6 @@
 // internal.h -- the two opaque objects of the C API and the pieces they own.
 #pragma once
+#include <array>
 #include <map>
 #include <memory>
 #include <string>
@@ -77,6 +78,16 @@ struct cudecompGridDesc {
   using HaloKey = std::tuple<int, int, std::array<int32_t, 6>, std::array<bool, 3>, bool>;
   std::map<HaloKey, cudecomp::HaloPlan> halo_plans;
 
+  // performance samples (CUDECOMP_ENABLE_PERFORMANCE_REPORT=1): per transpose op a ring of event quadruples
+  // [start, packed, exchanged, done] recorded on the caller's stream
+  struct PerfSample {
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool used = false;
+  };
+  std::array<std::vector<PerfSample>, 4> perf;
+  std::array<int64_t, 4> perf_calls{};
+  std::array<int64_t, 4> perf_bytes{};  // interior pencil bytes moved by the last call
+
   cudecompCommInfo& comm(cudecomp::CommAxis a) { return a == cudecomp::COMM_ROW ? row : col; }
   ~cudecompGridDesc();
 };
@@ -137,6 +148,20 @@ void runTranspose(cudecompHandle_t handle, cudecompGridDesc_t gd, TransposeOp op
 void runHalo(cudecompHandle_t handle, cudecompGridDesc_t gd, int axis, void* input, void* work,
              cudecompDataType_t dtype, const int32_t* halo, const bool* periods, int dim, const int32_t* pad,
              hipStream_t stream);
+
+// perf.cc
+struct TransposeTimings {
+  int64_t calls = 0, samples = 0;
+  double total_ms = 0, pack_ms = 0, exchange_ms = 0, unpack_ms = 0;  // averages over the retained samples
+  int64_t pencil_bytes = 0;
+};
+hipEvent_t* perfBegin(cudecompHandle_t h, cudecompGridDesc_t gd, int op, int64_t pencil_bytes, hipStream_t stream);
+inline void perfMark(hipEvent_t* ev, int which, hipStream_t stream) {
+  if (ev) (void)hipEventRecord(ev[which], stream);
+}
+TransposeTimings perfCollect(cudecompGridDesc_t gd, int op);  // synchronises the device
+void perfReport(cudecompHandle_t h, cudecompGridDesc_t gd);
+void perfReset(cudecompGridDesc_t gd);
 
 // autotune.cc
 void autotuneTranspose(cudecompHandle_t handle, cudecompGridDesc_t gd, const cudecompGridDescAutotuneOptions_t* opt,

@@ -57,6 +57,15 @@ class RcclContext {
 // ================================================================================================
 // PEER: IPC-mapped buffers + one-sided xGMI copies
 // ================================================================================================
+// Platform quirk (ROCm 7.x, dmabuf IPC): hipIpcOpenMemHandle never returns for an allocation whose byte size has
+// bit 31 set (2-4 GiB, 6-8 GiB, ...); every other size maps and transfers correctly (verified block by block with
+// cudecompExtPeerProbe up to 17 GiB).  Library allocations are rounded up past such sizes; foreign buffers of
+// such a size are refused instead of hanging.
+inline bool ipcSizeHangs(size_t bytes) { return (bytes & 0x80000000ull) != 0; }
+inline size_t ipcSafeSize(size_t bytes) {
+  return ipcSizeHangs(bytes) ? ((bytes >> 32) + 1) << 32 : bytes;
+}
+
 class PeerContext {
  public:
   struct Region {
@@ -140,6 +149,9 @@ class PeerContext {
       void* base = nullptr;
       size_t bytes = 0;
       CD_CHECK_HIP(hipMemGetAddressRange(&base, &bytes, const_cast<void*>(local)));
+      if (ipcSizeHangs(bytes))
+        CD_PEER_ERROR("this buffer's allocation (" + std::to_string(bytes) + " bytes) cannot be shared over IPC on this "
+                      "platform; obtain the workspace from cudecompMalloc");
       r = registerRegion(base, bytes, false);
     }
     char* pb = r->peer_base[global_rank];
@@ -244,6 +256,40 @@ void peerResetBarrierSlot(cudecompHandle_t h, int slot) {
   if (h->peer) h->peer->resetSlot(slot);
 }
 
+int peerProbe(cudecompHandle_t h, void* buffer, size_t bytes) {
+  if (h->nranks == 1) return 0;
+  if (!h->peer) CD_INVALID_USAGE("peer transport not active for this handle");
+  PeerContext& pc = *h->peer;
+  const size_t blk = 4096;
+  if (bytes < 4 * blk) CD_INVALID_USAGE("buffer too small to probe");
+  const int next = (h->rank + 1) % h->nranks, prev = (h->rank + h->nranks - 1) % h->nranks;
+  std::vector<size_t> offs = {0, (bytes / 2) & ~(blk - 1), (bytes - blk) & ~(blk - 1)};
+  for (size_t g = (size_t)1 << 30; g + blk <= bytes; g += (size_t)1 << 30) offs.push_back(g);  // every GiB boundary
+  std::vector<unsigned int> pat(blk / 4);
+  char* remote = pc.translate(buffer, next);
+  CD_CHECK_HIP(hipMemset(buffer, 0, bytes));
+  CD_CHECK_HIP(hipDeviceSynchronize());
+  h->boot->barrier();
+  for (size_t o : offs) {
+    for (size_t i = 0; i < pat.size(); ++i) pat[i] = (unsigned int)(0x9e3779b9u * (h->rank + 1) + o / blk * 2654435761u + i);
+    CD_CHECK_HIP(hipMemcpy(remote + o, pat.data(), blk, hipMemcpyHostToDevice));
+  }
+  CD_CHECK_HIP(hipDeviceSynchronize());
+  h->boot->barrier();
+  int bad = 0;
+  std::vector<unsigned int> got(blk / 4);
+  for (size_t o : offs) {
+    CD_CHECK_HIP(hipMemcpy(got.data(), static_cast<char*>(buffer) + o, blk, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < got.size(); ++i)
+      if (got[i] != (unsigned int)(0x9e3779b9u * (prev + 1) + o / blk * 2654435761u + i)) {
+        ++bad;
+        break;
+      }
+  }
+  h->boot->barrier();
+  return bad;
+}
+
 void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
   if (h->nranks == 1) return;  // every communicator has one member: nothing ever travels
   if (need_rccl && !h->rccl) {
@@ -258,6 +304,7 @@ void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
   if (h->nranks > 1 && peer_capable) {
     // one-sided writes address the peer's workspace by offset: make it the same size everywhere
     bytes = (size_t)h->boot->allreduceMaxI64((int64_t)bytes);
+    bytes = ipcSafeSize(bytes);
     prepareTransports(h, false, true);
     CD_CHECK_HIP(hipMalloc(&ptr, bytes));
     try {

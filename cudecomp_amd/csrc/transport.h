@@ -28,6 +28,9 @@ MPI_Comm commFromFortran(MPI_Fint f);
 void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer);
 
 void peerResetBarrierSlot(cudecompHandle_t h, int slot);
+// diagnostic: every rank writes a tagged block at several offsets of the NEXT rank's copy of `buffer` (a buffer
+// from cudecompMalloc, `bytes` long) and checks what the PREVIOUS rank wrote into its own; returns mismatches
+int peerProbe(cudecompHandle_t h, void* buffer, size_t bytes);
 
 void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes);  // collective
 // same, without a grid descriptor: peer_capable = map the buffer into the other ranks for one-sided writes

@@ -48,10 +48,14 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
 
   ensureDevice(h);
   void* bufs[3] = {input, output, work};
+  hipEvent_t* pev = perfBegin(h, gd, (int)op, plan.pencil_elements_a * es, stream);
 
   if (!plan.exchange) {
     launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
+    perfMark(pev, 1, stream);
+    perfMark(pev, 2, stream);
     launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
+    perfMark(pev, 3, stream);
     return;
   }
 
@@ -62,14 +66,20 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
 
   if (backend == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_SM) {
     // compute-unit driven: pack straight into the peers' receive areas
+    perfMark(pev, 1, stream);  // pack and exchange are one fused phase here: all of it counts as exchange
     peerPutExchange(h, ci, plan, bufs, es, stream);
+    perfMark(pev, 2, stream);
     launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
+    perfMark(pev, 3, stream);
     return;
   }
   if (!traits.pipelined) {
     launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
+    perfMark(pev, 1, stream);
     alltoallExchange(h, gd, ci, plan, xb, es, backend, stream);
+    perfMark(pev, 2, stream);
     launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
+    perfMark(pev, 3, stream);
     return;
   }
 
@@ -82,6 +92,7 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
     for (size_t i = old; i < gd->events.size(); ++i)
       CD_CHECK_HIP(hipEventCreateWithFlags(&gd->events[i], hipEventDisableTiming));
   }
+  perfMark(pev, 1, stream);
   if (!plan.pack.empty()) {
     for (const Move3D& m : plan.pack) {
       launchMoves(&m, 1, bufs, es, stream, &h->tuning);
@@ -97,6 +108,9 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
     for (const Move3D& m : plan.unpack)
       if (m.peer == src) launchMoves(&m, 1, bufs, es, stream, &h->tuning);
   }
+  // phases interleave in the per-peer pipeline: report the whole operation as exchange time
+  perfMark(pev, 2, stream);
+  perfMark(pev, 3, stream);
 }
 
 void runHalo(cudecompHandle_t h, cudecompGridDesc_t gd, int axis, void* input, void* work, cudecompDataType_t dtype,

@@ -62,6 +62,23 @@ cudecompResult_t cudecompExtGetHaloPlan(cudecompHandle_t handle, cudecompGridDes
                                         const int32_t halo_extents[], const bool halo_periods[], int32_t dim,
                                         const int32_t padding[], int32_t backend_override, cudecompExtHaloPlan_t* plan);
 
+/* Averages over the last (up to 32) calls of one transpose op, recorded when CUDECOMP_ENABLE_PERFORMANCE_REPORT=1
+ * was set at cudecompInit (0 calls otherwise).  Synchronises the device.  exchange_ms is the all-to-all
+ * (including host-side ordering for the host-ordered transports); per-peer pipelined backends report the
+ * whole operation as exchange. */
+typedef struct {
+  int64_t calls, samples;
+  double total_ms, pack_ms, exchange_ms, unpack_ms;
+  int64_t pencil_bytes;
+} cudecompExtTransposeTimings_t;
+cudecompResult_t cudecompExtGetTransposeTimings(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t op,
+                                                cudecompExtTransposeTimings_t* timings);
+
+/* Peer-transport self test (collective): every rank writes tagged 4 KiB blocks at the start, middle, end and
+ * every GiB boundary of the NEXT rank's copy of `buffer` (from cudecompMalloc, `bytes` long) and verifies what the
+ * previous rank wrote into its own.  *mismatches = number of wrong blocks (0 = the IPC mapping is sound). */
+cudecompResult_t cudecompExtPeerProbe(cudecompHandle_t handle, void* buffer, size_t bytes, int32_t* mismatches);
+
 /* Run one block move on the GPU (src/dst are device pointers, strides in elements of es bytes).
  * force_generic is a bit mask: 1 selects the element-wise fallback kernel, 2 forces the streaming
  * (non-temporal) variants that are normally used only for moves of 32 MiB and more.  *kernel_class (optional) receives the
