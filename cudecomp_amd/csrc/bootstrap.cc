@@ -248,7 +248,6 @@ class Hub {
 
 struct TcpShared {
   int fd = -1;
-  int world_rank = 0, world_size = 1;
   std::unique_ptr<Hub> hub;  // rank 0 only
   ~TcpShared() {
     if (fd >= 0) ::close(fd);
@@ -318,8 +317,6 @@ std::unique_ptr<Bootstrap> makeTcpBootstrap(const LaunchEnv& env, int instance) 
   auto sh = g_shared.lock();
   if (!sh) {
     sh = std::make_shared<TcpShared>();
-    sh->world_rank = env.rank;
-    sh->world_size = env.size;
 
     addrinfo hints{}, *res = nullptr;
     hints.ai_family = AF_INET;

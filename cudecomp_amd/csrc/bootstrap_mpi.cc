@@ -149,7 +149,6 @@ void mpiHaloExchange(cudecompHandle_t h, const HaloExchange& x, hipStream_t stre
   const int n = toInt(x.bytes, "halo backend");
   const bool aware = gpuAware();
   char *sbase = x.send, *rbase = x.recv;
-  i64 s_lo = 0, r_lo = 0;
   if (!aware) {
     // stage only the two faces / two slots
     g_stage.grow((size_t)2 * x.bytes, (size_t)2 * x.bytes);
@@ -158,8 +157,6 @@ void mpiHaloExchange(cudecompHandle_t h, const HaloExchange& x, hipStream_t stre
         CD_CHECK_HIP(hipMemcpy(g_stage.send + i * x.bytes, x.send + x.send_off[i], (size_t)x.bytes, hipMemcpyDeviceToHost));
   }
   MPI_Request reqs[4] = {MPI_REQUEST_NULL, MPI_REQUEST_NULL, MPI_REQUEST_NULL, MPI_REQUEST_NULL};
-  (void)s_lo;
-  (void)r_lo;
   for (int i = 0; i < 2; ++i) {
     if (x.neighbor[i] == -1) continue;
     // tags tell the two faces apart when both neighbours are the same rank: a face sent towards the low

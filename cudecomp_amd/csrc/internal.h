@@ -5,7 +5,6 @@
 #include <memory>
 #include <string>
 #include <tuple>
-#include <unordered_map>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -17,8 +16,8 @@
 #include "plan.h"
 
 namespace cudecomp {
-class RcclContext;  // transport_rccl.cc
-class PeerContext;  // transport_peer.cc
+class RcclContext;  // transport.cc
+class PeerContext;  // transport.cc
 }  // namespace cudecomp
 
 // One row or column of the process grid as seen by this rank.

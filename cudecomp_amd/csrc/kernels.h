@@ -20,10 +20,10 @@ struct KernelStats {  // filled per launch when requested (tests, bench bookkeep
 };
 
 struct KernelTuning {
-  int transpose_tile_log2 = 0;  // 0 = default
   int force_class = -1;         // tests: force MOVE_GENERIC (2) to cross-check the fast paths
   bool no_streaming = false;    // never use non-temporal access (CUDECOMP_DISABLE_STREAMING_ACCESS=1)
   bool force_streaming = false; // tests: non-temporal access regardless of the move size
+  int misaligned_store_mode = -1;  // tuning aid: streaming mode (0/1/2) for transposes with unaligned destination rows
 };
 
 // Execute `n` independent moves (disjoint destinations) of `es`-byte elements.  bufs[BufId] are the

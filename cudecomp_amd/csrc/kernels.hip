@@ -66,6 +66,17 @@ template <> struct BytesOf<8> { using type = u32x2; };
 template <> struct BytesOf<16> { using type = u32x4; };
 template <int N> using Bytes = typename BytesOf<N>::type;
 
+// The same payloads for GLOBAL memory at element (not vector) alignment.  gfx950 global loads/stores of 8 and
+// 16 bytes only need dword-aligned addresses, so a halo-shifted pencil (interior starting one fp64 past a 16-byte
+// boundary, say) still moves 16 bytes per lane; a wavefront then touches one extra cache line per KiB.
+typedef u32x2 __attribute__((aligned(4))) u32x2_g;
+typedef u32x4 __attribute__((aligned(4))) u32x4_g;
+template <int N> struct GlobalBytesOf;
+template <> struct GlobalBytesOf<4> { using type = unsigned int; };
+template <> struct GlobalBytesOf<8> { using type = u32x2_g; };
+template <> struct GlobalBytesOf<16> { using type = u32x4_g; };
+template <int N> using GlobalBytes = typename GlobalBytesOf<N>::type;
+
 // element v (ES bytes) of a VW-element vector
 template <int ES, int VW> struct Lane;
 template <int ES> struct Lane<ES, 1> {
@@ -90,15 +101,17 @@ template <> struct Lane<8, 2> {
 // Streaming (non-temporal) access for moves far larger than the caches: measured +3..15 % on the 1024^3
 // permutations (profiles/r01_tuning.md); small moves keep the default policy so a following kernel can
 // still find the data in L2 / Infinity Cache.
-template <bool STREAM, typename V>
-__device__ __forceinline__ V loadVec(const V* p) {
-  if constexpr (STREAM) return __builtin_nontemporal_load(p);
-  else return *p;
+template <bool STREAM, int N>
+__device__ __forceinline__ Bytes<N> loadVec(const void* p) {
+  const GlobalBytes<N>* q = static_cast<const GlobalBytes<N>*>(p);
+  if constexpr (STREAM) return __builtin_nontemporal_load(q);
+  else return *q;
 }
-template <bool STREAM, typename V>
-__device__ __forceinline__ void storeVec(V* p, const V& v) {
-  if constexpr (STREAM) __builtin_nontemporal_store(v, p);
-  else *p = v;
+template <bool STREAM, int N>
+__device__ __forceinline__ void storeVec(void* p, const Bytes<N>& v) {
+  GlobalBytes<N>* q = static_cast<GlobalBytes<N>*>(p);
+  if constexpr (STREAM) __builtin_nontemporal_store(v, q);
+  else *q = v;
 }
 
 __device__ __forceinline__ int findMove(const Batch& b, unsigned int block) {
@@ -110,7 +123,7 @@ __device__ __forceinline__ int findMove(const Batch& b, unsigned int block) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// rows_kernel: e[0] = vectors per row, e[1] = rows, e[2] = planes; ss/ds[1], [2] in vectors.
+// rows_kernel: e[0] = vectors per row, e[1] = rows, e[2] = planes; ss/ds[1], [2] in BYTES.
 // p0 = log2(lanes per row).  A workgroup covers (256 >> p0) * kRowsUnroll rows x (1 << p0) vectors.
 // ---------------------------------------------------------------------------------------------
 template <int VB, bool STREAM>
@@ -131,23 +144,23 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(const Batch b) {
   const long long col = (long long)bc * lpr + (threadIdx.x & (lpr - 1));
   const long long r0 = (long long)br * rb * kRowsUnroll + (threadIdx.x >> lg);
   if (col >= m.e[0]) return;
-  const V* __restrict__ s = reinterpret_cast<const V*>(m.src) + plane * m.ss[2] + col;
-  V* __restrict__ d = reinterpret_cast<V*>(m.dst) + plane * m.ds[2] + col;
+  const char* __restrict__ s = m.src + plane * m.ss[2] + col * VB;
+  char* __restrict__ d = m.dst + plane * m.ds[2] + col * VB;
 
   V v[kRowsUnroll];
 #pragma unroll
   for (int u = 0; u < kRowsUnroll; ++u) {
     const long long r = r0 + (long long)u * rb;
-    if (r < m.e[1]) v[u] = loadVec<STREAM>(s + r * m.ss[1]);
+    if (r < m.e[1]) v[u] = loadVec<STREAM, VB>(s + r * m.ss[1]);
   }
 #pragma unroll
   for (int u = 0; u < kRowsUnroll; ++u) {
     const long long r = r0 + (long long)u * rb;
-    if (r < m.e[1]) storeVec<STREAM>(d + r * m.ds[1], v[u]);
+    if (r < m.e[1]) storeVec<STREAM, VB>(d + r * m.ds[1], v[u]);
   }
 }
 
-template <int ES, int VW, int TI, int TJ, bool STREAM, bool GUARD>
+template <int ES, int VW, int TI, int TJ, int STREAM, bool GUARD>
 __device__ __forceinline__ void transposeTile(Bytes<ES>* tile, const Bytes<ES>* __restrict__ src,
                                               Bytes<ES>* __restrict__ dst, long long i0, long long j0, long long ei,
                                               long long ej, long long sj, long long di, int tid) {
@@ -169,7 +182,7 @@ __device__ __forceinline__ void transposeTile(Bytes<ES>* tile, const Bytes<ES>* 
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       if (!GUARD || (i0 + li < ei && j0 + lj + p * RPP < ej))
-        regs[p] = loadVec<STREAM>(reinterpret_cast<const V*>(base + (long long)(p * RPP) * sj));
+        regs[p] = loadVec<(STREAM >= 1), ES * VW>(base + (long long)(p * RPP) * sj);
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -191,7 +204,7 @@ __device__ __forceinline__ void transposeTile(Bytes<ES>* tile, const Bytes<ES>* 
 #pragma unroll
       for (int v = 0; v < VW; ++v) Lane<ES, VW>::set(out, v, tile[(lj + v) * PITCH + ii]);
       if (!GUARD || (i0 + ii < ei && j0 + lj < ej))
-        storeVec<STREAM>(reinterpret_cast<V*>(base + (long long)(p * RPO) * di), out);
+        storeVec<(STREAM >= 2), ES * VW>(base + (long long)(p * RPO) * di, out);
     }
   }
 }
@@ -200,7 +213,8 @@ __device__ __forceinline__ void transposeTile(Bytes<ES>* tile, const Bytes<ES>* 
 // transpose_kernel: dims (i, j, k): i is unit-stride in the source, j is unit-stride in the
 // destination, k is the batch dim.  e = {ei, ej, ek}; ss = {1, sj, sk}; ds = {di, 1, dk} (elements).
 // ---------------------------------------------------------------------------------------------
-template <int ES, int VW, int TI, int TJ, bool STREAM>
+// STREAM: 0 = default caching, 1 = non-temporal loads, 2 = non-temporal loads and stores
+template <int ES, int VW, int TI, int TJ, int STREAM>
 __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
   using E = Bytes<ES>;
   constexpr int PITCH = TI + 1;  // LDS row pitch in elements: +1 keeps column reads <= 2-way conflicted
@@ -276,13 +290,11 @@ struct Classified {
   int variant;  // rows: vector bytes; transpose: elements per vector
   DevMove dm;
   int p0, p1;
-  bool stream;
+  int stream;  // 0 default caching, 1 streaming loads, 2 streaming loads + stores
   unsigned int t0, t1;
   unsigned long long blocks;
   i64 elements;
 };
-
-inline bool aligned(const void* p, i64 a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 int ilog2ceil(long long x) {
   int l = 0;
@@ -300,29 +312,24 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
   normalizeMove(m);
   Classified c{};
   c.elements = m.elements();
-  c.stream = (c.elements * es >= kStreamBytes || (tuning && tuning->force_streaming)) && !(tuning && tuning->no_streaming);
+  c.stream = ((c.elements * es >= kStreamBytes || (tuning && tuning->force_streaming)) && !(tuning && tuning->no_streaming)) ? 2 : 0;
   c.dm.src = static_cast<const char*>(bufs[m.src_buf]) + m.src_off * es;
   c.dm.dst = static_cast<char*>(dst_base ? dst_base : bufs[m.dst_buf]) + m.dst_off * es;
   const bool force_generic = tuning && tuning->force_class == MOVE_GENERIC;
 
   if (!force_generic && m.ss[0] <= 1 && m.ds[0] <= 1) {
-    // rows contiguous on both sides (also the all-extents-1 case).  Widest vector the addresses allow.
+    // rows contiguous on both sides (also the all-extents-1 case).  Widest vector that divides the row length;
+    // addresses only need the element's natural alignment (see GlobalBytes).
     int vb = 16;
-    for (; vb > es; vb >>= 1) {
-      bool ok = aligned(c.dm.src, vb) && aligned(c.dm.dst, vb) && (m.extent[0] * es) % vb == 0;
-      for (int i = 1; i < 3 && ok; ++i) ok = (m.ss[i] * es) % vb == 0 && (m.ds[i] * es) % vb == 0;
-      if (ok) break;
-    }
-    if (vb < es) vb = es;
+    while (vb > es && (m.extent[0] * es) % vb != 0) vb >>= 1;
     c.cls = MOVE_ROWS_VEC;
     c.variant = vb;
-    const i64 scale = vb / es;  // elements per vector (vb >= es always holds here)
-    c.dm.e[0] = m.extent[0] / scale;
+    c.dm.e[0] = m.extent[0] * es / vb;
     c.dm.e[1] = m.extent[1];
     c.dm.e[2] = m.extent[2];
     for (int i = 1; i < 3; ++i) {
-      c.dm.ss[i] = m.ss[i] / scale;
-      c.dm.ds[i] = m.ds[i] / scale;
+      c.dm.ss[i] = m.ss[i] * es;
+      c.dm.ds[i] = m.ds[i] * es;
     }
     c.p0 = std::min(8, ilog2ceil(c.dm.e[0]));
     const long long lpr = 1LL << c.p0, rows_per_block = (long long)(kThreads >> c.p0) * kRowsUnroll;
@@ -349,15 +356,21 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     c.dm.ds[0] = m.ds[0];
     c.dm.ds[1] = 1;
     c.dm.ds[2] = m.ds[k];
+    // 16 bytes per lane whenever both tile edges hold whole vectors (no alignment requirement, see GlobalBytes)
     int vw = 16 / es;
-    if (vw > 1) {
-      const i64 vb = 16;
-      bool ok = aligned(c.dm.src, vb) && aligned(c.dm.dst, vb) && c.dm.e[0] % vw == 0 && c.dm.e[1] % vw == 0 &&
-                c.dm.ss[1] % vw == 0 && c.dm.ss[2] % vw == 0 && c.dm.ds[0] % vw == 0 && c.dm.ds[2] % vw == 0;
-      if (!ok) vw = 1;
-    }
+    if (c.dm.e[0] % vw != 0 || c.dm.e[1] % vw != 0) vw = 1;
     c.variant = vw;
     c.p1 = 1;  // XCD-contiguous tile walk
+    // Rows that do not start on cache-line boundaries (halo-shifted or odd-extent pencils) leave partially
+    // covered lines at both ends of every tile row.  Non-temporal access sends those to HBM as partial
+    // transactions; default caching lets L2 merge the neighbouring tiles' halves first (measured on a
+    // halo-shifted permutation: fp32 3.0 -> 4.4 TB/s, fp64 3.9 -> 4.8 TB/s).  Aligned moves keep streaming.
+    if (c.stream == 2) {
+      const uintptr_t bits = reinterpret_cast<uintptr_t>(c.dm.dst) | reinterpret_cast<uintptr_t>(c.dm.src) |
+                             (uintptr_t)(c.dm.ds[0] * es) | (uintptr_t)(c.dm.ds[2] * es) |
+                             (uintptr_t)(c.dm.ss[1] * es) | (uintptr_t)(c.dm.ss[2] * es);
+      if (bits % 128 != 0) c.stream = (tuning && tuning->misaligned_store_mode >= 0) ? tuning->misaligned_store_mode : 0;
+    }
     const int ti = (es == 16) ? 32 : 64, tj = ti;
     c.t0 = (unsigned int)((c.dm.e[0] + ti - 1) / ti);
     c.t1 = (unsigned int)((c.dm.e[1] + tj - 1) / tj);
@@ -380,14 +393,15 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
   return c;
 }
 
-template <bool STREAM>
+template <int STREAM>
 void launchBatchT(MoveClass cls, int variant, int es, const Batch& b, unsigned int blocks, hipStream_t stream) {
   const dim3 grid(blocks), block(kThreads);
+  constexpr bool ROWS_STREAM = STREAM >= 1;
   switch (cls) {
     case MOVE_ROWS_VEC:
-      if (variant == 16) rows_kernel<16, STREAM><<<grid, block, 0, stream>>>(b);
-      else if (variant == 8) rows_kernel<8, STREAM><<<grid, block, 0, stream>>>(b);
-      else rows_kernel<4, STREAM><<<grid, block, 0, stream>>>(b);
+      if (variant == 16) rows_kernel<16, ROWS_STREAM><<<grid, block, 0, stream>>>(b);
+      else if (variant == 8) rows_kernel<8, ROWS_STREAM><<<grid, block, 0, stream>>>(b);
+      else rows_kernel<4, ROWS_STREAM><<<grid, block, 0, stream>>>(b);
       break;
     case MOVE_TRANSPOSE:
       if (es == 4) {
@@ -409,10 +423,11 @@ void launchBatchT(MoveClass cls, int variant, int es, const Batch& b, unsigned i
   CD_CHECK_HIP(hipGetLastError());
 }
 
-void launchBatch(MoveClass cls, int variant, bool stream_access, int es, const Batch& b, unsigned int blocks,
+void launchBatch(MoveClass cls, int variant, int stream_access, int es, const Batch& b, unsigned int blocks,
                  hipStream_t stream) {
-  if (stream_access) launchBatchT<true>(cls, variant, es, b, blocks, stream);
-  else launchBatchT<false>(cls, variant, es, b, blocks, stream);
+  if (stream_access == 2) launchBatchT<2>(cls, variant, es, b, blocks, stream);
+  else if (stream_access == 1) launchBatchT<1>(cls, variant, es, b, blocks, stream);
+  else launchBatchT<0>(cls, variant, es, b, blocks, stream);
 }
 
 }  // namespace

@@ -1,0 +1,96 @@
+// Library-kernel survey: achieved GB/s of launchMoves for the move shapes the transposes produce, per element
+// size and access path (vector / scalar lanes).  Tuning aid, not part of the product.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "kernels.h"
+#define CK(x)                                                              \
+  do {                                                                     \
+    hipError_t e = (x);                                                    \
+    if (e != hipSuccess) {                                                 \
+      printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__);     \
+      exit(1);                                                             \
+    }                                                                      \
+  } while (0)
+using cudecomp::Move3D;
+
+static cudecomp::KernelTuning g_tuning;
+static float timeMove(const Move3D& m, char* src, char* dst, int es, int reps = 10) {
+  void* bufs[3] = {src, dst, nullptr};
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  cudecomp::launchMoves(&m, 1, bufs, es, nullptr, &g_tuning);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) cudecomp::launchMoves(&m, 1, bufs, es, nullptr, &g_tuning);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+static Move3D mk(long long e0, long long e1, long long e2, long long s0, long long s1, long long s2, long long d0,
+                 long long d1, long long d2, long long soff = 0, long long doff = 0) {
+  Move3D m;
+  m.src_buf = cudecomp::BUF_IN;
+  m.dst_buf = cudecomp::BUF_OUT;
+  m.extent[0] = e0;
+  m.extent[1] = e1;
+  m.extent[2] = e2;
+  m.ss[0] = s0;
+  m.ss[1] = s1;
+  m.ss[2] = s2;
+  m.ds[0] = d0;
+  m.ds[1] = d1;
+  m.ds[2] = d2;
+  m.src_off = soff;
+  m.dst_off = doff;
+  return m;
+}
+
+struct Case {
+  const char* name;
+  Move3D m;
+};
+
+int main() {
+  const size_t bytes = (size_t)9 << 30;
+  char *src, *dst;
+  CK(hipMalloc(&src, bytes));
+  CK(hipMalloc(&dst, bytes));
+  CK(hipMemset(src, 1, bytes));
+  struct Cfg {
+    int es;
+    long long A, B, C;
+  } cfgs[] = {{4, 2048, 1024, 1024}, {8, 1024, 1024, 1024}, {16, 512, 1024, 1024}};
+  for (auto& c : cfgs) {
+    const long long A = c.A, B = c.B, C = c.C;
+    std::vector<Case> v;
+    v.push_back({"copy (rows)", mk(A, B, C, 1, A, A * B, 1, A, A * B)});
+    v.push_back({"fwd perm (y,z,x)", mk(A, B, C, 1, A, A * B, B * C, 1, B)});
+    v.push_back({"bwd perm (z,x,y)", mk(A, B, C, 1, A, A * B, C, C * A, 1)});
+    v.push_back({"swap xy (y,x,z)", mk(A, B, C, 1, A, A * B, B, 1, A * B)});
+    v.push_back({"fwd perm, +1 element offset (scalar lanes)",
+                 mk(A - 2, B - 2, C, 1, A, A * B, (B - 2) * C, 1, B - 2, 1, 1)});
+    v.push_back({"rows, halo-1 interior (scalar lanes)",
+                 mk(A - 2, B - 2, C - 2, 1, A, A * B, 1, A, A * B, 1 + A + A * B, 1 + A + A * B)});
+    v.push_back({"pack 1/8 slab along x (short rows)", mk(A / 8, B, C, 1, A, A * B, 1, A / 8, A / 8 * B)});
+    printf("== element size %d bytes, block %lld x %lld x %lld\n", c.es, A, B, C);
+    for (auto& k : v) {
+      double b = 2.0 * k.m.elements() * c.es;
+      printf("  %-44s", k.name);
+      for (int mode = 2; mode >= 0; --mode) {
+        g_tuning.misaligned_store_mode = mode;
+        float ms = timeMove(k.m, src, dst, c.es);
+        printf(" | mode %d: %7.3f ms %6.0f GB/s", mode, ms, b / ms / 1e6);
+      }
+      printf("\n");
+    }
+  }
+  return 0;
+}
