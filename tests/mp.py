@@ -70,3 +70,37 @@ if __name__ == "__main__":
     result = getattr(importlib.import_module(module), func)(rank, nranks, json.loads(args))
     with open(out, "w") as f:
         json.dump(result, f)
+
+
+def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
+    """Launch a native executable (C / Fortran test twin) on N ranks with the same launcher environment;
+    returns the list of per-rank stdout+stderr texts, raising on any non-zero exit."""
+    port_a, port_b = free_port(), free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "WORLD_SIZE": str(nranks), "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port_a), "CUDECOMP_BOOTSTRAP_PORT": str(port_b),
+                    "CUDECOMP_BOOTSTRAP_TIMEOUT": "60", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([str(a) for a in argv], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    logs, failures = [], []
+    for r, p in enumerate(procs):
+        try:
+            log, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            log, _ = p.communicate()
+            failures.append("rank %d timed out\n%s" % (r, log.decode(errors="replace")[-4000:]))
+            continue
+        text = log.decode(errors="replace")
+        logs.append(text)
+        if p.returncode != 0:
+            failures.append("rank %d exit %s\n%s" % (r, p.returncode, text[-4000:]))
+    if failures:
+        raise AssertionError("\n".join(failures))
+    return logs
