@@ -66,6 +66,12 @@ def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_
 if __name__ == "__main__":
     import importlib
     module, func, args, out = sys.argv[1:5]
+    if os.environ.get("CUDECOMP_TEST_RCCL_SHIM"):
+        # tests/shim: make the stand-in's nccl* symbols global BEFORE libcudecomp.so is loaded, after torch so that
+        # its HIP dependency binds to the runtime already in the process (same order rule as cudecomp_amd.lib())
+        import ctypes
+        import torch  # noqa: F401
+        ctypes.CDLL(os.environ["CUDECOMP_TEST_RCCL_SHIM"], mode=ctypes.RTLD_GLOBAL)
     rank, nranks = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     result = getattr(importlib.import_module(module), func)(rank, nranks, json.loads(args))
     with open(out, "w") as f:

@@ -1,0 +1,223 @@
+// fake_rccl.cc -- TEST-ONLY stand-in for the handful of RCCL entry points libcudecomp.so calls.
+//
+// Why: RCCL refuses to place several ranks on one device, and the GPU boxes the tests run on have one GPU, so
+// the library's RCCL transport (grouped send/recv in transport.cc, the pipelined per-peer variant, the halo
+// pair exchange, ncclAllToAll for slab grids, RCCL candidates in the autotuner) could otherwise only be
+// exercised with a one-rank world.  LD_PRELOADing this shim lets N processes sharing the GPU run exactly that
+// library code; only the bytes-on-the-wire part underneath ncclSend/ncclRecv is replaced.  It is not part of
+// the product, is never loaded by it, and says nothing about RCCL performance.
+//
+// Semantics kept: point-to-point matching is FIFO per (source, destination) pair; operations inside a
+// ncclGroupStart/End pair are issued together and cannot deadlock against the peer's group; a send/recv
+// observes all work previously enqueued on its stream.  Difference: every call completes synchronously on
+// the host (the real library is stream-asynchronous), which is strictly more ordering, not less.
+//
+// Wire: one file per message under /dev/shm, written under a temporary name and renamed into place (atomic
+// publish); the receiver polls for its next expected name, copies it to the device and unlinks it.
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct FakeComm {
+  int rank = 0, nranks = 1;
+  uint64_t job = 0;
+  std::vector<uint64_t> sent, received;  // per peer message counters
+};
+
+struct Op {
+  bool is_send;
+  void* buf;
+  size_t bytes;
+  int peer;
+  FakeComm* comm;
+  hipStream_t stream;
+};
+
+thread_local int g_depth = 0;
+thread_local std::vector<Op> g_ops;
+
+size_t typeSize(ncclDataType_t t) {
+  switch ((int)t) {
+    case 0: case 1: return 1;          // int8 / uint8 (char)
+    case 2: case 3: case 7: return 4;  // int32 / uint32 / float32
+    case 4: case 5: case 8: return 8;  // int64 / uint64 / float64
+    case 6: case 9: return 2;          // float16 / bfloat16
+    default: return 1;
+  }
+}
+
+std::string mailbox(const FakeComm* c, int src, int dst, uint64_t seq) {
+  char name[160];
+  std::snprintf(name, sizeof(name), "/dev/shm/fakerccl_%016llx_%d_%d_%llu", (unsigned long long)c->job, src, dst,
+                (unsigned long long)seq);
+  return name;
+}
+
+double timeoutSeconds() {
+  const char* e = std::getenv("FAKE_RCCL_TIMEOUT");
+  return e ? std::atof(e) : 60.0;
+}
+
+ncclResult_t doSend(const Op& op) {
+  FakeComm* c = op.comm;
+  const std::string name = mailbox(c, c->rank, op.peer, c->sent[op.peer]++);
+  const std::string tmp = name + ".tmp";
+  int fd = ::open(tmp.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0600);
+  if (fd < 0) return ncclSystemError;
+  if (op.bytes) {
+    if (::ftruncate(fd, (off_t)op.bytes) != 0) return ncclSystemError;
+    void* m = ::mmap(nullptr, op.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) return ncclSystemError;
+    if (hipMemcpy(m, op.buf, op.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    ::munmap(m, op.bytes);
+  }
+  ::close(fd);
+  if (::rename(tmp.c_str(), name.c_str()) != 0) return ncclSystemError;
+  return ncclSuccess;
+}
+
+ncclResult_t doRecv(const Op& op) {
+  FakeComm* c = op.comm;
+  const std::string name = mailbox(c, op.peer, c->rank, c->received[op.peer]++);
+  const auto t0 = std::chrono::steady_clock::now();
+  int fd = -1;
+  while ((fd = ::open(name.c_str(), O_RDONLY)) < 0) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSeconds()) {
+      std::fprintf(stderr, "fake_rccl: rank %d timed out waiting for %s\n", c->rank, name.c_str());
+      return ncclSystemError;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  struct stat st;
+  ::fstat(fd, &st);
+  ncclResult_t res = ncclSuccess;
+  if ((size_t)st.st_size != op.bytes) {
+    std::fprintf(stderr, "fake_rccl: rank %d expected %zu bytes from %d, message has %lld\n", c->rank, op.bytes, op.peer,
+                 (long long)st.st_size);
+    res = ncclInvalidArgument;  // mismatched send/recv sizes would hang or corrupt with the real library
+  } else if (op.bytes) {
+    void* m = ::mmap(nullptr, op.bytes, PROT_READ, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) {
+      res = ncclSystemError;
+    } else {
+      if (hipMemcpy(op.buf, m, op.bytes, hipMemcpyHostToDevice) != hipSuccess) res = ncclUnhandledCudaError;
+      ::munmap(m, op.bytes);
+    }
+  }
+  ::close(fd);
+  ::unlink(name.c_str());
+  return res;
+}
+
+ncclResult_t flush() {
+  std::vector<Op> ops;
+  ops.swap(g_ops);
+  // everything already enqueued on the ops' streams must be visible to the copies below
+  for (size_t i = 0; i < ops.size(); ++i) {
+    bool seen = false;
+    for (size_t j = 0; j < i; ++j) seen = seen || ops[j].stream == ops[i].stream;
+    if (!seen && hipStreamSynchronize(ops[i].stream) != hipSuccess) return ncclUnhandledCudaError;
+  }
+  for (const Op& op : ops)
+    if (op.is_send) {
+      ncclResult_t r = doSend(op);
+      if (r != ncclSuccess) return r;
+    }
+  for (const Op& op : ops)
+    if (!op.is_send) {
+      ncclResult_t r = doRecv(op);
+      if (r != ncclSuccess) return r;
+    }
+  return ncclSuccess;
+}
+
+ncclResult_t enqueue(bool is_send, void* buf, size_t count, ncclDataType_t dtype, int peer, ncclComm_t comm,
+                     hipStream_t stream) {
+  FakeComm* c = reinterpret_cast<FakeComm*>(comm);
+  if (!c || peer < 0 || peer >= c->nranks) return ncclInvalidArgument;
+  g_ops.push_back(Op{is_send, buf, count * typeSize(dtype), peer, c, stream});
+  return g_depth == 0 ? flush() : ncclSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+  std::memset(id, 0, sizeof(*id));
+  const uint64_t v = ((uint64_t)::getpid() << 32) ^
+                     (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+  std::memcpy(id->internal, &v, sizeof(v));
+  std::memcpy(id->internal + 8, "FAKERCCL", 8);
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
+  if (std::memcmp(id.internal + 8, "FAKERCCL", 8) != 0) return ncclInvalidArgument;
+  FakeComm* c = new FakeComm;
+  c->rank = rank;
+  c->nranks = nranks;
+  std::memcpy(&c->job, id.internal, sizeof(c->job));
+  c->sent.assign(nranks, 0);
+  c->received.assign(nranks, 0);
+  *comm = reinterpret_cast<ncclComm_t>(c);
+  if (std::getenv("FAKE_RCCL_VERBOSE")) std::fprintf(stderr, "fake_rccl: rank %d of %d up\n", rank, nranks);
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm) {
+  delete reinterpret_cast<FakeComm*>(comm);
+  return ncclSuccess;
+}
+
+const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake_rccl error"; }
+
+ncclResult_t ncclGroupStart() {
+  ++g_depth;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclGroupEnd() {
+  if (g_depth <= 0) return ncclInvalidUsage;
+  return --g_depth == 0 ? flush() : ncclSuccess;
+}
+
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm,
+                      hipStream_t stream) {
+  return enqueue(true, const_cast<void*>(sendbuff), count, datatype, peer, comm, stream);
+}
+
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm,
+                      hipStream_t stream) {
+  return enqueue(false, recvbuff, count, datatype, peer, comm, stream);
+}
+
+ncclResult_t ncclAllToAll(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclComm_t comm,
+                          hipStream_t stream) {
+  FakeComm* c = reinterpret_cast<FakeComm*>(comm);
+  if (!c) return ncclInvalidArgument;
+  const size_t chunk = count * typeSize(datatype);
+  ++g_depth;
+  for (int p = 0; p < c->nranks; ++p) {
+    enqueue(true, const_cast<char*>(static_cast<const char*>(sendbuff)) + (size_t)p * chunk, count, datatype, p, comm,
+            stream);
+    enqueue(false, static_cast<char*>(recvbuff) + (size_t)p * chunk, count, datatype, p, comm, stream);
+  }
+  return --g_depth == 0 ? flush() : ncclSuccess;
+}
+
+}  // extern "C"
