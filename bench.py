@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--backend", default="auto", help="auto | nccl | nccl_pl | peer | peer_pl")
     ap.add_argument("--pdims", type=int, nargs=2, default=None)
     ap.add_argument("--inplace", action="store_true")
+    ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU runs: give up after this many seconds (0 = never)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="grid edge of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -102,6 +103,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and args.watchdog > 0:
+        # A multi-GPU run that wedges (a dead peer, a link that never completes) must not hold the node: after
+        # --watchdog seconds every rank reports where it was and exits non-zero.
+        import faulthandler
+        import threading
+
+        def _expired():
+            sys.stderr.write("bench.py: watchdog expired after %d s on rank %d\n" % (args.watchdog, rank))
+            faulthandler.dump_traceback(file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(3)
+
+        wd = threading.Timer(args.watchdog, _expired)
+        wd.daemon = True
+        wd.start()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))

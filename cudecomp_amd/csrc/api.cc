@@ -317,6 +317,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->graphs_enable = envIsOne("CUDECOMP_ENABLE_CUDA_GRAPHS");
     h->performance_report_enable = envIsOne("CUDECOMP_ENABLE_PERFORMANCE_REPORT");
     h->tuning.no_streaming = envIsOne("CUDECOMP_DISABLE_STREAMING_ACCESS");
+    if (const char* v = std::getenv("CUDECOMP_TILE_WALK")) h->tuning.walk_order = (int)std::strtol(v, nullptr, 10);  // tuning aid
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))
       if (std::strtol(v, nullptr, 10) == 1) h->tuning.force_class = MOVE_GENERIC;
 

@@ -238,10 +238,21 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
     const unsigned int per = nb >> 3;
     if (lb < (per << 3)) lt = (lb & 7u) * per + (lb >> 3);
   }
-  const unsigned int bi = lt % ti_n;
-  const unsigned int rest = lt / ti_n;
-  const unsigned int bj = rest % tj_n;
-  const long long k = rest / tj_n;
+  // Walk first along the tile dim that keeps the far-strided side on the same rows (same DRAM pages / TLB
+  // entries): i first extends the source rows, j first extends the destination rows.
+  unsigned int bi, bj, rest;
+  if (b.p1[mi] & 2) {
+    bj = lt % tj_n;
+    rest = lt / tj_n;
+    bi = rest % ti_n;
+    rest /= ti_n;
+  } else {
+    bi = lt % ti_n;
+    rest = lt / ti_n;
+    bj = rest % tj_n;
+    rest /= tj_n;
+  }
+  const long long k = rest;
 
   const long long i0 = (long long)bi * TI, j0 = (long long)bj * TJ;
   const long long ei = m.e[0], ej = m.e[1];
@@ -361,16 +372,26 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     if (c.dm.e[0] % vw != 0 || c.dm.e[1] % vw != 0) vw = 1;
     c.variant = vw;
     c.p1 = 1;  // XCD-contiguous tile walk
+    // Tile walk order inside an XCD's run: j first makes consecutive tiles extend the same DESTINATION rows
+    // (contiguous write stream per row), i first the same source rows.  Measured on 8 GiB permutations
+    // (profiles/r01_tuning.md): j first wins or ties for line-aligned moves (8-11 % at 16-byte elements and on
+    // the strided-read side at 4-byte elements; 4-byte moves whose destination rows are the far-strided side
+    // lose 1-3 % and keep i first), i first wins by 5-10 % for misaligned moves, where L2 merges the
+    // partially read lines of neighbouring tiles.
+    bool j_first = es != 4 || c.dm.ss[1] > c.dm.ds[0];
     // Rows that do not start on cache-line boundaries (halo-shifted or odd-extent pencils) leave partially
     // covered lines at both ends of every tile row.  Non-temporal access sends those to HBM as partial
     // transactions; default caching lets L2 merge the neighbouring tiles' halves first (measured on a
     // halo-shifted permutation: fp32 3.0 -> 4.4 TB/s, fp64 3.9 -> 4.8 TB/s).  Aligned moves keep streaming.
-    if (c.stream == 2) {
-      const uintptr_t bits = reinterpret_cast<uintptr_t>(c.dm.dst) | reinterpret_cast<uintptr_t>(c.dm.src) |
-                             (uintptr_t)(c.dm.ds[0] * es) | (uintptr_t)(c.dm.ds[2] * es) |
-                             (uintptr_t)(c.dm.ss[1] * es) | (uintptr_t)(c.dm.ss[2] * es);
-      if (bits % 128 != 0) c.stream = (tuning && tuning->misaligned_store_mode >= 0) ? tuning->misaligned_store_mode : 0;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(c.dm.dst) | reinterpret_cast<uintptr_t>(c.dm.src) |
+                           (uintptr_t)(c.dm.ds[0] * es) | (uintptr_t)(c.dm.ds[2] * es) |
+                           (uintptr_t)(c.dm.ss[1] * es) | (uintptr_t)(c.dm.ss[2] * es);
+    if (bits % 128 != 0) {
+      if (c.stream == 2) c.stream = (tuning && tuning->misaligned_store_mode >= 0) ? tuning->misaligned_store_mode : 0;
+      j_first = false;
     }
+    if (tuning && tuning->walk_order >= 0) j_first = tuning->walk_order == 1;
+    if (j_first) c.p1 |= 2;
     const int ti = (es == 16) ? 32 : 64, tj = ti;
     c.t0 = (unsigned int)((c.dm.e[0] + ti - 1) / ti);
     c.t1 = (unsigned int)((c.dm.e[1] + tj - 1) / tj);

@@ -84,10 +84,15 @@ int main() {
     for (auto& k : v) {
       double b = 2.0 * k.m.elements() * c.es;
       printf("  %-44s", k.name);
-      for (int mode = 2; mode >= 0; --mode) {
-        g_tuning.misaligned_store_mode = mode;
+      for (int walk = 0; walk <= 1; ++walk) {
+        g_tuning.walk_order = walk;
         float ms = timeMove(k.m, src, dst, c.es);
-        printf(" | mode %d: %7.3f ms %6.0f GB/s", mode, ms, b / ms / 1e6);
+        printf(" | %s first: %7.3f ms %6.0f GB/s", walk ? "j" : "i", ms, b / ms / 1e6);
+      }
+      g_tuning.walk_order = -1;
+      {
+        float ms = timeMove(k.m, src, dst, c.es);
+        printf(" | auto: %7.3f ms %6.0f GB/s", ms, b / ms / 1e6);
       }
       printf("\n");
     }
