@@ -275,10 +275,7 @@ cudecompHandle::~cudecompHandle() {
 }
 
 cudecompGridDesc::~cudecompGridDesc() {
-  for (auto& ring : perf)
-    for (auto& s : ring)
-      for (hipEvent_t e : s.ev)
-        if (e) (void)hipEventDestroy(e);
+  cudecomp::perfDestroy(this);
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
 }
 
@@ -316,6 +313,22 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
 
     h->graphs_enable = envIsOne("CUDECOMP_ENABLE_CUDA_GRAPHS");
     h->performance_report_enable = envIsOne("CUDECOMP_ENABLE_PERFORMANCE_REPORT");
+    // report options, docs/env_vars.rst of the reference (defaults 0 / 20 / 3 / unset; bad values warn and keep them)
+    auto envInt = [&](const char* name, int lo, int hi, int dflt) {
+      const char* v = std::getenv(name);
+      if (!v || !*v) return dflt;
+      char* end = nullptr;
+      const long x = std::strtol(v, &end, 10);
+      if (*end != '\0' || x < lo || x > hi) {
+        if (h->rank == 0) printf("CUDECOMP:WARN: Invalid %s value (%s). Using default (%d).\n", name, v, dflt);
+        return dflt;
+      }
+      return (int)x;
+    };
+    h->performance_report_detail = envInt("CUDECOMP_PERFORMANCE_REPORT_DETAIL", 0, 2, 0);
+    h->performance_report_samples = envInt("CUDECOMP_PERFORMANCE_REPORT_SAMPLES", 1, 1 << 20, 20);
+    h->performance_report_warmup_samples = envInt("CUDECOMP_PERFORMANCE_REPORT_WARMUP_SAMPLES", 0, 1 << 30, 3);
+    if (const char* v = std::getenv("CUDECOMP_PERFORMANCE_REPORT_WRITE_DIR")) h->performance_report_write_dir = v;
     h->tuning.no_streaming = envIsOne("CUDECOMP_DISABLE_STREAMING_ACCESS");
     if (const char* v = std::getenv("CUDECOMP_TILE_WALK")) h->tuning.walk_order = (int)std::strtol(v, nullptr, 10);  // tuning aid
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))

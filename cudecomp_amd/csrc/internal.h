@@ -50,6 +50,10 @@ struct cudecompHandle {
   // environment switches (same names as the reference, docs/env_vars.rst)
   bool graphs_enable = false;
   bool performance_report_enable = false;
+  int performance_report_detail = 0;          // 0 summary, 1 + samples of rank 0, 2 + samples of all ranks
+  int performance_report_samples = 20;        // ring size per configuration
+  int performance_report_warmup_samples = 3;  // first calls of a configuration that are not sampled
+  std::string performance_report_write_dir;   // CSV output directory ("" = none)
   bool col_major_env_warned = false;
 
   cudecomp::KernelTuning tuning;
@@ -77,15 +81,23 @@ struct cudecompGridDesc {
   using HaloKey = std::tuple<int, int, std::array<int32_t, 6>, std::array<bool, 3>, bool>;
   std::map<HaloKey, cudecomp::HaloPlan> halo_plans;
 
-  // performance samples (CUDECOMP_ENABLE_PERFORMANCE_REPORT=1): per transpose op a ring of event quadruples
-  // [start, packed, exchanged, done] recorded on the caller's stream
+  // performance samples (CUDECOMP_ENABLE_PERFORMANCE_REPORT=1), one ring of event quadruples
+  // [start, local phase 1 done, exchange done, end] per distinct call configuration, recorded on the caller's stream
   struct PerfSample {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool used = false;
   };
-  std::array<std::vector<PerfSample>, 4> perf;
-  std::array<int64_t, 4> perf_calls{};
-  std::array<int64_t, 4> perf_bytes{};  // interior pencil bytes moved by the last call
+  struct PerfCollection {
+    std::vector<PerfSample> ring;
+    int64_t calls = 0;       // calls seen, warm-up included
+    int64_t wire_bytes = 0;  // bytes the exchange moved in the last call (reference: transpose.h:316, halo.h:236)
+  };
+  // (op, dtype, [in halo, out halo, in pad, out pad], in place)
+  using TransposePerfKey = std::tuple<int, int, std::array<int32_t, 12>, bool>;
+  // (axis, dim, dtype, halo, periods, padding)
+  using HaloPerfKey = std::tuple<int, int, int, std::array<int32_t, 3>, std::array<bool, 3>, std::array<int32_t, 3>>;
+  std::map<TransposePerfKey, PerfCollection> perf_transpose;
+  std::map<HaloPerfKey, PerfCollection> perf_halo;
 
   cudecompCommInfo& comm(cudecomp::CommAxis a) { return a == cudecomp::COMM_ROW ? row : col; }
   ~cudecompGridDesc();
@@ -154,13 +166,19 @@ struct TransposeTimings {
   double total_ms = 0, pack_ms = 0, exchange_ms = 0, unpack_ms = 0;  // averages over the retained samples
   int64_t pencil_bytes = 0;
 };
-hipEvent_t* perfBegin(cudecompHandle_t h, cudecompGridDesc_t gd, int op, int64_t pencil_bytes, hipStream_t stream);
+hipEvent_t* perfBeginTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, int op, cudecompDataType_t dtype,
+                               const std::array<int32_t, 12>& halos_pads, bool inplace, int64_t wire_bytes,
+                               hipStream_t stream);
+hipEvent_t* perfBeginHalo(cudecompHandle_t h, cudecompGridDesc_t gd, int axis, int dim, cudecompDataType_t dtype,
+                          const std::array<int32_t, 3>& halo, const std::array<bool, 3>& periods,
+                          const std::array<int32_t, 3>& padding, int64_t wire_bytes, hipStream_t stream);
 inline void perfMark(hipEvent_t* ev, int which, hipStream_t stream) {
   if (ev) (void)hipEventRecord(ev[which], stream);
 }
-TransposeTimings perfCollect(cudecompGridDesc_t gd, int op);  // synchronises the device
-void perfReport(cudecompHandle_t h, cudecompGridDesc_t gd);
+TransposeTimings perfCollect(cudecompGridDesc_t gd, int op);  // all configurations of one op; synchronises the device
+void perfReport(cudecompHandle_t h, cudecompGridDesc_t gd);   // collective
 void perfReset(cudecompGridDesc_t gd);
+void perfDestroy(cudecompGridDesc_t gd);
 
 // autotune.cc
 void autotuneTranspose(cudecompHandle_t handle, cudecompGridDesc_t gd, const cudecompGridDescAutotuneOptions_t* opt,

@@ -48,7 +48,7 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
 
   ensureDevice(h);
   void* bufs[3] = {input, output, work};
-  hipEvent_t* pev = perfBegin(h, gd, (int)op, plan.pencil_elements_a * es, stream);
+  hipEvent_t* pev = perfBeginTranspose(h, gd, (int)op, dtype, hp, inplace, plan.exchange ? plan.pencil_elements_a * es : 0, stream);
 
   if (!plan.exchange) {
     launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
@@ -134,8 +134,16 @@ void runHalo(cudecompHandle_t h, cudecompGridDesc_t gd, int axis, void* input, v
 
   ensureDevice(h);
   void* bufs[3] = {input, input, work};
+  int64_t wire_bytes = 0;
+  if (plan.kind != HaloPlan::SELF_PERIODIC)
+    for (int i = 0; i < 2; ++i)
+      if (plan.neighbor[i] >= 0) wire_bytes += plan.face_elements * es;
+  hipEvent_t* pev = perfBeginHalo(h, gd, axis, dim, dtype, hh, per, pp, wire_bytes, stream);
   if (plan.kind == HaloPlan::SELF_PERIODIC) {
     launchMoves(plan.pre.data(), (int)plan.pre.size(), bufs, es, stream, &h->tuning);
+    perfMark(pev, 1, stream);
+    perfMark(pev, 2, stream);
+    perfMark(pev, 3, stream);
     return;
   }
   HaloExchange x;
@@ -149,8 +157,11 @@ void runHalo(cudecompHandle_t h, cudecompGridDesc_t gd, int axis, void* input, v
   x.bytes = plan.face_elements * es;
   x.comm_axis = plan.comm_axis;
   if (plan.kind == HaloPlan::PACKED) launchMoves(plan.pre.data(), (int)plan.pre.size(), bufs, es, stream, &h->tuning);
+  perfMark(pev, 1, stream);
   haloExchange(h, gd, x, backend, stream);
+  perfMark(pev, 2, stream);
   if (plan.kind == HaloPlan::PACKED) launchMoves(plan.post.data(), (int)plan.post.size(), bufs, es, stream, &h->tuning);
+  perfMark(pev, 3, stream);
 }
 
 }  // namespace cudecomp

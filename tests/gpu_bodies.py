@@ -261,3 +261,39 @@ def halo_sampled(rank, nranks, args):
         torch.cuda.empty_cache()
     cd.cudecompGridDescDestroy(h, gd)
     return failures
+
+
+def perf_report(rank, nranks, args):
+    """Repeat the transpose cycle and two halo updates on ONE descriptor with the performance report enabled
+    (environment set by the launcher before cudecompInit); return the CSV files rank 0 finds after the
+    descriptor was destroyed."""
+    import glob
+    outdir = os.environ["CUDECOMP_PERFORMANCE_REPORT_WRITE_DIR"]
+    h, gd, g = _setup(rank, nranks, args)
+    kind = args.get("kind", 1)
+    dt, es = orc.KINDS[kind]
+    halo = (1, 1, 1)
+    pin = [cd.cudecompGetPencilInfo(h, gd, ax, halo) for ax in range(3)]
+    nel = max(p.size for p in pin)
+    work = cd.cudecompMalloc(h, gd, max(cd.cudecompGetTransposeWorkspaceSize(h, gd),
+                                        max(cd.cudecompGetHaloWorkspaceSize(h, gd, ax, halo) for ax in range(3))) * es)
+    a = torch.zeros(nel * es, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(nel * es, dtype=torch.uint8, device="cuda")
+    for _ in range(args.get("repeat", 4)):
+        cur, nxt = a, b
+        for op in cd.OPS:
+            cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DTYPE_OF_KIND[kind], None, None,
+                                 None, None, G.stream_ptr())
+            cur, nxt = nxt, cur
+        for axis, dim in ((0, 1), (1, 2)):
+            cd.cudecompUpdateHalos(axis, h, gd, a.data_ptr(), work, cd.DTYPE_OF_KIND[kind], halo, (True, True, True),
+                                   dim, None, G.stream_ptr())
+    torch.cuda.synchronize()
+    cd.cudecompFree(h, gd, work)
+    cd.cudecompGridDescDestroy(h, gd)  # collective; rank 0 prints the report and writes the CSV files
+    files = {}
+    if rank == 0:
+        for f in sorted(glob.glob(os.path.join(outdir, "*.csv"))):
+            with open(f) as fh:
+                files[os.path.basename(f)] = fh.read()
+    return {"files": files}
