@@ -104,7 +104,7 @@ API_SYMBOLS = [
     "cudecompUpdateHalosY", "cudecompUpdateHalosZ",
 ]
 EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecompExtMove3D",
-               "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe"]
+               "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe", "cudecompExtGetGraphStats"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -169,6 +169,7 @@ def lib():
                                              C.POINTER(ExtHaloPlan)]
         L.cudecompExtGetTransposeTimings.argtypes = [vp, vp, i32, C.POINTER(ExtTransposeTimings)]
         L.cudecompExtPeerProbe.argtypes = [vp, vp, C.c_size_t, pi32]
+        L.cudecompExtGetGraphStats.argtypes = [vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cudecompExtMove3D.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32, pi32, vp]
         _lib = L
     return _lib
@@ -318,6 +319,12 @@ def cudecompExtGetTransposeTimings(handle, gd, op):
     t = ExtTransposeTimings()
     _check(lib().cudecompExtGetTransposeTimings(handle, gd, OPS.index(op), C.byref(t)), "cudecompExtGetTransposeTimings")
     return {k: getattr(t, k) for k, _ in ExtTransposeTimings._fields_}
+
+
+def cudecompExtGetGraphStats(handle, gd):
+    captured, launches = C.c_int64(0), C.c_int64(0)
+    _check(lib().cudecompExtGetGraphStats(handle, gd, C.byref(captured), C.byref(launches)), "cudecompExtGetGraphStats")
+    return captured.value, launches.value
 
 
 def cudecompExtPeerProbe(handle, buffer, nbytes):

@@ -277,6 +277,8 @@ cudecompHandle::~cudecompHandle() {
 cudecompGridDesc::~cudecompGridDesc() {
   cudecomp::perfDestroy(this);
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
+  for (auto& kv : pack_graphs) (void)hipGraphExecDestroy(kv.second);
+  if (graph_stream) (void)hipStreamDestroy(graph_stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,7 +313,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->local_rank = h->rank_to_local_rank[h->rank];
     h->local_nranks = seen[h->hostnames[h->rank]];
 
-    h->graphs_enable = envIsOne("CUDECOMP_ENABLE_CUDA_GRAPHS");
+    h->graphs_enable = envIsOne("CUDECOMP_ENABLE_CUDA_GRAPHS") || envIsOne("CUDECOMP_ENABLE_HIP_GRAPHS");
     h->performance_report_enable = envIsOne("CUDECOMP_ENABLE_PERFORMANCE_REPORT");
     // report options, docs/env_vars.rst of the reference (defaults 0 / 20 / 3 / unset; bad values warn and keep them)
     auto envInt = [&](const char* name, int lo, int hi, int dflt) {

@@ -143,6 +143,22 @@ cudecompResult_t cudecompExtGetTransposeTimings(cudecompHandle_t handle, cudecom
   return CUDECOMP_RESULT_SUCCESS;
 }
 
+cudecompResult_t cudecompExtGetGraphStats(cudecompHandle_t handle, cudecompGridDesc_t gd, int64_t* captured,
+                                          int64_t* launches) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    if (!gd || !gd->initialized || gd->handle != handle) CD_INVALID_USAGE("invalid grid descriptor");
+    if (!captured || !launches) CD_INVALID_USAGE("null argument");
+    *captured = (int64_t)gd->pack_graphs.size();
+    *launches = gd->graph_launches;
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
 cudecompResult_t cudecompExtPeerProbe(cudecompHandle_t handle, void* buffer, size_t bytes, int32_t* mismatches) {
   try {
     if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");

@@ -75,11 +75,21 @@ struct cudecompGridDesc {
 
   std::vector<hipEvent_t> events;  // one per communicator member, for per-peer pipelining
 
+
   // plan caches (key: op, halos, padding, in-place flag, transport traits)
   using TransposeKey = std::tuple<int, std::array<int32_t, 12>, bool, bool, bool>;
   std::map<TransposeKey, cudecomp::TransposePlan> transpose_plans;
   using HaloKey = std::tuple<int, int, std::array<int32_t, 6>, std::array<bool, 3>, bool>;
   std::map<HaloKey, cudecomp::HaloPlan> halo_plans;
+
+  // CUDECOMP_ENABLE_CUDA_GRAPHS=1: the per-peer pack loop of the pipelined backends (one kernel + one event
+  // record per destination) is captured once per (plan, buffers, element size) and replayed as one graph launch
+  // (reference: graphCache, src/graph.cc, include/internal/transpose.h:458-519)
+  using PackGraphKey = std::tuple<TransposeKey, const void*, const void*, const void*, int>;
+  std::map<PackGraphKey, hipGraphExec_t> pack_graphs;
+  hipStream_t graph_stream = nullptr;
+  int64_t graph_launches = 0;
+  bool graphs_failed = false;  // the runtime refused a capture: stay on plain launches
 
   // performance samples (CUDECOMP_ENABLE_PERFORMANCE_REPORT=1), one ring of event quadruples
   // [start, local phase 1 done, exchange done, end] per distinct call configuration, recorded on the caller's stream

@@ -1,5 +1,7 @@
 // transpose.cc -- executes transpose and halo plans: bind pointers, launch the move kernels, run the
 // exchange.  The algorithmic content lives in plan.cc (what moves where) and kernels.hip (how).
+#include <cstdio>
+
 #include "errors.h"
 #include "internal.h"
 #include "transport.h"
@@ -11,6 +13,60 @@ namespace {
 
 std::array<int32_t, 3> arr3(const int32_t* p) {
   return p ? std::array<int32_t, 3>{p[0], p[1], p[2]} : std::array<int32_t, 3>{0, 0, 0};
+}
+
+// Capture [pack kernel of destination d -> record events[d]] for every destination into an executable graph.
+// Returns nullptr (and switches graphs off for this descriptor, with one warning) if the runtime refuses.
+hipGraphExec_t capturePackLoop(cudecompHandle_t h, cudecompGridDesc_t gd, const TransposePlan& plan, void* const* bufs,
+                               int es) {
+  auto give_up = [&](const char* what, hipError_t e) -> hipGraphExec_t {
+    (void)hipGetLastError();
+    gd->graphs_failed = true;
+    if (h->rank == 0)
+      fprintf(stderr, "CUDECOMP:WARN: graph capture of the pipelined pack loop failed (%s: %s); continuing without graphs\n",
+              what, hipGetErrorString(e));
+    return nullptr;
+  };
+  hipError_t e;
+  if (!gd->graph_stream && (e = hipStreamCreateWithFlags(&gd->graph_stream, hipStreamNonBlocking)) != hipSuccess)
+    return give_up("hipStreamCreate", e);
+  hipStream_t gs = gd->graph_stream;
+  if ((e = hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal)) != hipSuccess) return give_up("begin capture", e);
+  const char* failed = nullptr;
+  try {
+    for (const Move3D& m : plan.pack) {
+      launchMoves(&m, 1, bufs, es, gs, &h->tuning);
+      hipStreamCaptureStatus status;
+      unsigned long long id = 0;
+      hipGraph_t capturing = nullptr;
+      const hipGraphNode_t* deps = nullptr;
+      size_t ndeps = 0;
+      if ((e = hipStreamGetCaptureInfo_v2(gs, &status, &id, &capturing, &deps, &ndeps)) != hipSuccess) {
+        failed = "capture info";
+        break;
+      }
+      hipGraphNode_t record = nullptr;
+      if ((e = hipGraphAddEventRecordNode(&record, capturing, deps, ndeps, gd->events[m.peer])) != hipSuccess) {
+        failed = "event record node";
+        break;
+      }
+    }
+  } catch (const Error&) {
+    failed = "kernel launch";
+    e = hipErrorUnknown;
+  }
+  hipGraph_t graph = nullptr;
+  const hipError_t end = hipStreamEndCapture(gs, &graph);
+  if (failed) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return give_up(failed, e);
+  }
+  if (end != hipSuccess) return give_up("end capture", end);
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return give_up("instantiate", e);
+  return exec;
 }
 
 }  // namespace
@@ -94,9 +150,28 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
   }
   perfMark(pev, 1, stream);
   if (!plan.pack.empty()) {
-    for (const Move3D& m : plan.pack) {
-      launchMoves(&m, 1, bufs, es, stream, &h->tuning);
-      CD_CHECK_HIP(hipEventRecord(gd->events[m.peer], stream));
+    // With graphs enabled the loop is captured once on a private stream -- each destination's kernel followed by an
+    // event-record NODE hanging off it, so the side stream can wait on the per-peer events after the launch --
+    // and replayed as ONE graph launch on later calls with the same buffers.
+    hipGraphExec_t exec = nullptr;
+    if (h->graphs_enable && !gd->graphs_failed && plan.pack.size() > 1) {
+      const cudecompGridDesc::PackGraphKey gkey{key, input, output, work, es};
+      auto git = gd->pack_graphs.find(gkey);
+      if (git != gd->pack_graphs.end()) {
+        exec = git->second;
+      } else {
+        exec = capturePackLoop(h, gd, plan, bufs, es);
+        if (exec) gd->pack_graphs.emplace(gkey, exec);
+      }
+    }
+    if (exec) {
+      CD_CHECK_HIP(hipGraphLaunch(exec, stream));
+      gd->graph_launches++;
+    } else {
+      for (const Move3D& m : plan.pack) {
+        launchMoves(&m, 1, bufs, es, stream, &h->tuning);
+        CD_CHECK_HIP(hipEventRecord(gd->events[m.peer], stream));
+      }
     }
   } else {
     for (int d = 0; d < P; ++d) CD_CHECK_HIP(hipEventRecord(gd->events[d], stream));

@@ -79,6 +79,11 @@ cudecompResult_t cudecompExtGetTransposeTimings(cudecompHandle_t handle, cudecom
  * previous rank wrote into its own.  *mismatches = number of wrong blocks (0 = the IPC mapping is sound). */
 cudecompResult_t cudecompExtPeerProbe(cudecompHandle_t handle, void* buffer, size_t bytes, int32_t* mismatches);
 
+/* Graph statistics of a descriptor (CUDECOMP_ENABLE_CUDA_GRAPHS=1): number of distinct pack loops captured and
+ * number of graph launches issued so far (captures included).  Both stay 0 when graphs are off or were refused. */
+cudecompResult_t cudecompExtGetGraphStats(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int64_t* captured,
+                                          int64_t* launches);
+
 /* Run one block move on the GPU (src/dst are device pointers, strides in elements of es bytes).
  * force_generic is a bit mask: 1 selects the element-wise fallback kernel, 2 forces the streaming
  * (non-temporal) variants that are normally used only for moves of 32 MiB and more.  *kernel_class (optional) receives the

@@ -297,3 +297,41 @@ def perf_report(rank, nranks, args):
             with open(f) as fh:
                 files[os.path.basename(f)] = fh.read()
     return {"files": files}
+
+
+def repeated_cycle(rank, nranks, args):
+    """The X->Y->Z->Y->X cycle several times on the SAME buffers with a check after every hop: cached plans, and with
+    CUDECOMP_ENABLE_CUDA_GRAPHS=1 the captured pack loop of the pipelined backends, are replayed from the
+    second iteration on."""
+    h, gd, g = _setup(rank, nranks, args)
+    kind = args.get("kind", 1)
+    dt, es = orc.KINDS[kind]
+    pin = [cd.cudecompGetPencilInfo(h, gd, ax) for ax in range(3)]
+    opin = [g.pencil_info(rank, ax) for ax in range(3)]
+    nel = max(p.size for p in pin)
+    work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * es)
+    a = torch.zeros(nel * es, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(nel * es, dtype=torch.uint8, device="cuda")
+    failures = []
+    for it in range(args.get("iterations", 3)):
+        init = np.full(nel, -7, dtype=dt)
+        init[:pin[0].size] = g.fill_pencil(opin[0], kind)
+        a.copy_(torch.from_numpy(init.view(np.uint8)))
+        b.fill_(0x5A)
+        cur, nxt = a, b
+        for op in cd.OPS:
+            ai, ao = orc.OP_AXES[op]
+            cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DTYPE_OF_KIND[kind], None, None,
+                                 None, None, G.stream_ptr())
+            torch.cuda.synchronize()
+            got = G.to_host(nxt).view(dt)[:pin[ao].size].copy()
+            exp = g.fill_pencil(opin[ao], kind)
+            bad = orc.compare_pencil(opin[ao], kind, exp, got, True)
+            if bad:
+                failures.append("rank %d iteration %d %s: mismatch at %d" % (rank, it, op, bad - 1))
+            cur.fill_(0xA5)  # a stale replay that re-read the old input would show up in the next hop
+            cur, nxt = nxt, cur
+    graphs = cd.cudecompExtGetGraphStats(h, gd)
+    cd.cudecompFree(h, gd, work)
+    cd.cudecompGridDescDestroy(h, gd)
+    return {"failures": failures, "graphs": graphs}

@@ -1,0 +1,31 @@
+"""CUDECOMP_ENABLE_CUDA_GRAPHS=1: the pipelined backends capture their per-peer pack loop (kernel + external event
+record per destination) into a hipGraph and replay it on later calls with the same buffers (reference:
+src/graph.cc, include/internal/transpose.h:458-519).  Results must not change, replays included."""
+import os
+
+import pytest
+
+import cudecomp_amd as cd
+from tests import cases as K
+from tests.mp import ROOT, run_ranks
+
+pytestmark = pytest.mark.gpu
+SHIM = os.path.join(ROOT, "tests", "shim", "libfake_rccl.so")
+
+
+@pytest.mark.parametrize("n,pdims", [(2, (2, 1)), (4, (2, 2)), (4, (1, 4)), (3, (3, 1))])
+@pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_NCCL_PL], ids=["peer_pl", "nccl_pl"])
+def test_pipelined_pack_loop_graph_replay(n, pdims, backend):
+    env = {"CUDECOMP_ENABLE_CUDA_GRAPHS": "1"}
+    if backend == cd.TRANSPOSE_COMM_NCCL_PL:
+        if not os.path.exists(SHIM):
+            pytest.skip("tests/shim/libfake_rccl.so not built")
+        env["CUDECOMP_TEST_RCCL_SHIM"] = SHIM  # several ranks on one GPU, see tests/test_gpu_rccl_path.py
+    for ac in (K.ALL_AC, K.DEFAULT_AC):
+        args = {"gdims": (96, 80, 112), "pdims": pdims, "ac": ac, "kind": 1, "transpose_backend": backend,
+                "iterations": 3}
+        for r in run_ranks(n, "tests.gpu_bodies", "repeated_cycle", args, timeout=300, extra_env=env):
+            assert r["failures"] == []
+            captured, launches = r["graphs"]
+            # every op whose pack phase addresses more than one destination captured once and launched 3 times
+            assert captured >= 1 and launches == 3 * captured, r["graphs"]
