@@ -316,13 +316,13 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->graphs_enable = envIsOne("CUDECOMP_ENABLE_CUDA_GRAPHS") || envIsOne("CUDECOMP_ENABLE_HIP_GRAPHS");
     h->performance_report_enable = envIsOne("CUDECOMP_ENABLE_PERFORMANCE_REPORT");
     // report options, docs/env_vars.rst of the reference (defaults 0 / 20 / 3 / unset; bad values warn and keep them)
-    auto envInt = [&](const char* name, int lo, int hi, int dflt) {
-      const char* v = std::getenv(name);
+    auto envInt = [&](const char* var, int lo, int hi, int dflt) {
+      const char* v = std::getenv(var);
       if (!v || !*v) return dflt;
       char* end = nullptr;
       const long x = std::strtol(v, &end, 10);
       if (*end != '\0' || x < lo || x > hi) {
-        if (h->rank == 0) printf("CUDECOMP:WARN: Invalid %s value (%s). Using default (%d).\n", name, v, dflt);
+        if (h->rank == 0) printf("CUDECOMP:WARN: Invalid %s value (%s). Using default (%d).\n", var, v, dflt);
         return dflt;
       }
       return (int)x;

@@ -138,3 +138,15 @@ def test_fortran_halo_update(case):
     argv = [_binary("halo_test"), *gd, *pd, backend, axis, *halo, *periods, *pad, ac]
     rec = _records(run_binary_ranks(nranks, argv))
     assert sorted(r[0] for r in rec["PASS"]) == list(range(nranks))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_fortran_basic_usage_example(nranks):
+    exe = os.path.join(BUILD, "basic_usage_f")
+    if not os.path.exists(exe):
+        if shutil.which("amdflang") is None:
+            pytest.skip("no Fortran compiler (amdflang) and no prebuilt example")
+        subprocess.run(["make", "-C", os.path.join(ROOT, "fortran"), "example"], check=True, capture_output=True)
+    logs = run_binary_ranks(nranks, [exe])
+    assert sum("round trip OK" in text for text in logs) == nranks, logs
