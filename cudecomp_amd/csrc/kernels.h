@@ -23,6 +23,7 @@ struct KernelTuning {
   int force_class = -1;         // tests: force MOVE_GENERIC (2) to cross-check the fast paths
   bool no_streaming = false;    // never use non-temporal access (CUDECOMP_DISABLE_STREAMING_ACCESS=1)
   bool force_streaming = false; // tests: non-temporal access regardless of the move size
+  int stream_alignment = 0;        // tuning aid: alignment (bytes) below which transposes use cached access (0 = 128)
   int walk_order = -1;             // tuning aid: transposes walk tiles i first (0) / j first (1); -1 = by strides
   int misaligned_store_mode = -1;  // tuning aid: streaming mode (0/1/2) for transposes with unaligned destination rows
 };

@@ -386,7 +386,8 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     const uintptr_t bits = reinterpret_cast<uintptr_t>(c.dm.dst) | reinterpret_cast<uintptr_t>(c.dm.src) |
                            (uintptr_t)(c.dm.ds[0] * es) | (uintptr_t)(c.dm.ds[2] * es) |
                            (uintptr_t)(c.dm.ss[1] * es) | (uintptr_t)(c.dm.ss[2] * es);
-    if (bits % 128 != 0) {
+    const uintptr_t align_req = (tuning && tuning->stream_alignment > 0) ? (uintptr_t)tuning->stream_alignment : 128;
+    if (bits % align_req != 0) {
       if (c.stream == 2) c.stream = (tuning && tuning->misaligned_store_mode >= 0) ? tuning->misaligned_store_mode : 0;
       j_first = false;
     }

@@ -80,6 +80,13 @@ int main() {
     v.push_back({"rows, halo-1 interior (scalar lanes)",
                  mk(A - 2, B - 2, C - 2, 1, A, A * B, 1, A, A * B, 1 + A + A * B, 1 + A + A * B)});
     v.push_back({"pack 1/8 slab along x (short rows)", mk(A / 8, B, C, 1, A, A * B, 1, A / 8, A / 8 * B)});
+    // padded pencils (the API's padding arguments): strides no longer powers of two
+    {
+      const long long P = 128 / c.es;  // one cache line of padding on the fastest dim of both sides
+      v.push_back({"fwd perm, rows padded by 128 B", mk(A, B, C, 1, A + P, (A + P) * B, (B + P) * C, 1, B + P)});
+      v.push_back({"bwd perm, rows padded by 128 B", mk(A, B, C, 1, A + P, (A + P) * B, C + P, (C + P) * A, 1)});
+      v.push_back({"fwd perm, dst plane padded by 4 KiB", mk(A, B, C, 1, A, A * B, B * C + 4096 / c.es, 1, B)});
+    }
     printf("== element size %d bytes, block %lld x %lld x %lld\n", c.es, A, B, C);
     for (auto& k : v) {
       double b = 2.0 * k.m.elements() * c.es;
@@ -94,6 +101,12 @@ int main() {
         float ms = timeMove(k.m, src, dst, c.es);
         printf(" | auto: %7.3f ms %6.0f GB/s", ms, b / ms / 1e6);
       }
+      for (int al : {512, 4096}) {
+        g_tuning.stream_alignment = al;
+        float ms = timeMove(k.m, src, dst, c.es);
+        printf(" | cached unless %d-aligned: %7.3f ms", al, ms);
+      }
+      g_tuning.stream_alignment = 0;
       printf("\n");
     }
   }
