@@ -141,6 +141,10 @@ def main():
 
     if world > 1:
         os.environ["CUDECOMP_ENABLE_PERFORMANCE_REPORT"] = "1"  # per-op local / exchange split, reported below
+        # keep exactly the timed calls: the library skips its first WARMUP_SAMPLES calls per op (our warm-up steps;
+        # the autotuner's trials are dropped by the library itself) and retains the last SAMPLES
+        os.environ["CUDECOMP_PERFORMANCE_REPORT_WARMUP_SAMPLES"] = str(args.warmup)
+        os.environ["CUDECOMP_PERFORMANCE_REPORT_SAMPLES"] = str(max(args.steps, 1))
     h = cd.cudecompInit()
     autotuned = None
     if world == 1:
