@@ -92,6 +92,11 @@ class ExtHaloPlan(C.Structure):
                 ("send_off", C.c_int64 * 2), ("recv_off", C.c_int64 * 2), ("pre", ExtMove * 2), ("post", ExtMove * 2)]
 
 
+class ExtGridSpec(C.Structure):
+    _fields_ = [("gdims", C.c_int32 * 3), ("gdims_dist", C.c_int32 * 3), ("pdims", C.c_int32 * 2),
+                ("col_major", C.c_int32), ("mem_order", (C.c_int32 * 3) * 3)]
+
+
 # every symbol include/cudecomp.h and include/cudecomp_ext.h declare (checked by tests/test_abi.py)
 API_SYMBOLS = [
     "cudecompInit", "cudecompInit_F", "cudecompFinalize", "cudecompGridDescCreateVersioned",
@@ -104,7 +109,8 @@ API_SYMBOLS = [
     "cudecompUpdateHalosY", "cudecompUpdateHalosZ",
 ]
 EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecompExtMove3D",
-               "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe", "cudecompExtGetGraphStats"]
+               "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe", "cudecompExtGetGraphStats",
+               "cudecompExtPlanTranspose", "cudecompExtPlanHalo"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -170,6 +176,10 @@ def lib():
         L.cudecompExtGetTransposeTimings.argtypes = [vp, vp, i32, C.POINTER(ExtTransposeTimings)]
         L.cudecompExtPeerProbe.argtypes = [vp, vp, C.c_size_t, pi32]
         L.cudecompExtGetGraphStats.argtypes = [vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cudecompExtPlanTranspose.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, pi32, pi32, C.c_bool, i32,
+                                               i32, i32, C.POINTER(ExtTransposePlan)]
+        L.cudecompExtPlanHalo.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, C.POINTER(C.c_bool), i32, pi32, i32,
+                                          C.POINTER(ExtHaloPlan)]
         L.cudecompExtMove3D.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32, pi32, vp]
         _lib = L
     return _lib
@@ -319,6 +329,35 @@ def cudecompExtGetTransposeTimings(handle, gd, op):
     t = ExtTransposeTimings()
     _check(lib().cudecompExtGetTransposeTimings(handle, gd, OPS.index(op), C.byref(t)), "cudecompExtGetTransposeTimings")
     return {k: getattr(t, k) for k, _ in ExtTransposeTimings._fields_}
+
+
+def make_grid_spec(gdims, pdims, mem_order, gdims_dist=None, col_major=False):
+    g = ExtGridSpec()
+    for i in range(3):
+        g.gdims[i] = gdims[i]
+        g.gdims_dist[i] = gdims_dist[i] if gdims_dist else 0
+        for j in range(3):
+            g.mem_order[i][j] = mem_order[i][j]
+    g.pdims[0], g.pdims[1] = pdims
+    g.col_major = 1 if col_major else 0
+    return g
+
+
+def cudecompExtPlanTranspose(grid, rank, op, in_halo=None, out_halo=None, in_pad=None, out_pad=None, inplace=False,
+                             pipelined=False, symmetric_recv=False, npergroup=0):
+    """Stateless planner (no handle, no communicator): the plan of `rank` in the decomposition `grid`."""
+    p = ExtTransposePlan()
+    _check(lib().cudecompExtPlanTranspose(C.byref(grid), rank, OPS.index(op), _i3(in_halo), _i3(out_halo), _i3(in_pad),
+                                          _i3(out_pad), bool(inplace), int(pipelined), int(symmetric_recv), npergroup,
+                                          C.byref(p)), "cudecompExtPlanTranspose")
+    return p
+
+
+def cudecompExtPlanHalo(grid, rank, axis, halo_extents, halo_periods, dim, padding=None, force_packed=False):
+    p = ExtHaloPlan()
+    _check(lib().cudecompExtPlanHalo(C.byref(grid), rank, axis, _i3(halo_extents), _b3(halo_periods), dim, _i3(padding),
+                                     int(force_packed), C.byref(p)), "cudecompExtPlanHalo")
+    return p
 
 
 def cudecompExtGetGraphStats(handle, gd):

@@ -30,6 +30,72 @@ void exportMove(const Move3D& m, cudecompExtMove_t* o) {
   o->reserved = 0;
 }
 
+void exportTransposePlan(const TransposePlan& p, const std::vector<int>& global_ranks, cudecompExtTransposePlan_t* out) {
+    if (p.nranks > CUDECOMP_EXT_MAX_MEMBERS) CD_NOT_SUPPORTED("communicator too large for cudecompExtTransposePlan_t");
+    std::memset(out, 0, sizeof(*out));
+    out->noop = p.noop;
+    out->exchange = p.exchange;
+    out->comm_axis = p.comm_axis;
+    out->nranks = p.nranks;
+    out->comm_rank = p.comm_rank;
+    out->send_buf = p.send_buf;
+    out->recv_buf = p.recv_buf;
+    out->send_base = p.send_base;
+    out->recv_base = p.recv_base;
+    out->n_pack = (int32_t)p.pack.size();
+    out->n_unpack = (int32_t)p.unpack.size();
+    for (int i = 0; i < p.nranks; ++i) {
+      out->member_global_rank[i] = global_ranks[i];
+      if (p.exchange) {
+        out->send_cnt[i] = p.send_cnt[i];
+        out->send_off[i] = p.send_off[i];
+        out->recv_cnt[i] = p.recv_cnt[i];
+        out->recv_off[i] = p.recv_off[i];
+        out->remote_recv_off[i] = p.remote_recv_off[i];
+      }
+      out->schedule_dst[i] = p.schedule_dst[i];
+    }
+    for (size_t i = 0; i < p.pack.size(); ++i) exportMove(p.pack[i], &out->pack[i]);
+    for (size_t i = 0; i < p.unpack.size(); ++i) exportMove(p.unpack[i], &out->unpack[i]);
+}
+
+void exportHaloPlan(const HaloPlan& p, cudecompExtHaloPlan_t* out) {
+    std::memset(out, 0, sizeof(*out));
+    out->kind = (int32_t)p.kind;
+    out->comm_axis = p.comm_axis;
+    out->xbuf = p.xbuf;
+    out->face_elements = p.face_elements;
+    for (int i = 0; i < 2; ++i) {
+      out->neighbor[i] = p.neighbor[i];
+      out->send_off[i] = p.send_off[i];
+      out->recv_off[i] = p.recv_off[i];
+    }
+    out->n_pre = (int32_t)p.pre.size();
+    out->n_post = (int32_t)p.post.size();
+    for (size_t i = 0; i < p.pre.size(); ++i) exportMove(p.pre[i], &out->pre[i]);
+    for (size_t i = 0; i < p.post.size(); ++i) exportMove(p.post[i], &out->post[i]);
+}
+
+GridShape shapeFromSpec(const cudecompExtGridSpec_t* spec) {
+  if (!spec) CD_INVALID_USAGE("grid spec cannot be null");
+  GridShape g;
+  for (int i = 0; i < 3; ++i) {
+    g.gdims[i] = spec->gdims[i];
+    g.gdims_dist[i] = spec->gdims_dist[i] > 0 ? spec->gdims_dist[i] : spec->gdims[i];
+    if (g.gdims[i] < 1 || g.gdims_dist[i] > g.gdims[i]) CD_INVALID_USAGE("bad gdims / gdims_dist in grid spec");
+    bool seen[3] = {false, false, false};
+    for (int j = 0; j < 3; ++j) {
+      const int v = spec->mem_order[i][j];
+      if (v < 0 || v > 2 || seen[v]) CD_INVALID_USAGE("mem_order rows of a grid spec must be permutations of 0,1,2");
+      seen[v] = true;
+      g.mem_order[i][j] = v;
+    }
+  }
+  g.pdims = {spec->pdims[0], spec->pdims[1]};
+  if (g.pdims[0] < 1 || g.pdims[1] < 1) CD_INVALID_USAGE("bad pdims in grid spec");
+  g.col_major = spec->col_major != 0;
+  return g;
+}
 
 }  // namespace
 
@@ -53,32 +119,7 @@ cudecompResult_t cudecompExtGetTransposePlan(cudecompHandle_t handle, cudecompGr
     const cudecompCommInfo& ci = gd->comm(ca);
     const TransposePlan p = buildTransposePlan(gd->shape, handle->rank, (TransposeOp)op, in_halo, out_halo, in_pad,
                                                out_pad, inplace, traits, ci.npergroup);
-    if (p.nranks > CUDECOMP_EXT_MAX_MEMBERS) CD_NOT_SUPPORTED("communicator too large for cudecompExtTransposePlan_t");
-    std::memset(out, 0, sizeof(*out));
-    out->noop = p.noop;
-    out->exchange = p.exchange;
-    out->comm_axis = p.comm_axis;
-    out->nranks = p.nranks;
-    out->comm_rank = p.comm_rank;
-    out->send_buf = p.send_buf;
-    out->recv_buf = p.recv_buf;
-    out->send_base = p.send_base;
-    out->recv_base = p.recv_base;
-    out->n_pack = (int32_t)p.pack.size();
-    out->n_unpack = (int32_t)p.unpack.size();
-    for (int i = 0; i < p.nranks; ++i) {
-      out->member_global_rank[i] = ci.global_ranks[i];
-      if (p.exchange) {
-        out->send_cnt[i] = p.send_cnt[i];
-        out->send_off[i] = p.send_off[i];
-        out->recv_cnt[i] = p.recv_cnt[i];
-        out->recv_off[i] = p.recv_off[i];
-        out->remote_recv_off[i] = p.remote_recv_off[i];
-      }
-      out->schedule_dst[i] = p.schedule_dst[i];
-    }
-    for (size_t i = 0; i < p.pack.size(); ++i) exportMove(p.pack[i], &out->pack[i]);
-    for (size_t i = 0; i < p.unpack.size(); ++i) exportMove(p.unpack[i], &out->unpack[i]);
+    exportTransposePlan(p, ci.global_ranks, out);
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {
@@ -99,20 +140,7 @@ cudecompResult_t cudecompExtGetHaloPlan(cudecompHandle_t handle, cudecompGridDes
     const int32_t zero[3] = {0, 0, 0};
     const HaloPlan p = buildHaloPlan(gd->shape, handle->rank, axis, dim, halo, periods, pad ? pad : zero,
                                      usesPeerTransport(handle, backend));
-    std::memset(out, 0, sizeof(*out));
-    out->kind = (int32_t)p.kind;
-    out->comm_axis = p.comm_axis;
-    out->xbuf = p.xbuf;
-    out->face_elements = p.face_elements;
-    for (int i = 0; i < 2; ++i) {
-      out->neighbor[i] = p.neighbor[i];
-      out->send_off[i] = p.send_off[i];
-      out->recv_off[i] = p.recv_off[i];
-    }
-    out->n_pre = (int32_t)p.pre.size();
-    out->n_post = (int32_t)p.post.size();
-    for (size_t i = 0; i < p.pre.size(); ++i) exportMove(p.pre[i], &out->pre[i]);
-    for (size_t i = 0; i < p.post.size(); ++i) exportMove(p.post[i], &out->post[i]);
+    exportHaloPlan(p, out);
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {
@@ -135,6 +163,54 @@ cudecompResult_t cudecompExtGetTransposeTimings(cudecompHandle_t handle, cudecom
     out->exchange_ms = t.exchange_ms;
     out->unpack_ms = t.unpack_ms;
     out->pencil_bytes = t.pencil_bytes;
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtPlanTranspose(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t op,
+                                          const int32_t in_halo[], const int32_t out_halo[], const int32_t in_pad[],
+                                          const int32_t out_pad[], bool inplace, int32_t pipelined,
+                                          int32_t symmetric_recv, int32_t npergroup, cudecompExtTransposePlan_t* out) {
+  try {
+    const GridShape g = shapeFromSpec(grid);
+    if (!out) CD_INVALID_USAGE("plan argument cannot be null");
+    if (op < 0 || op > 3) CD_INVALID_USAGE("op out of range");
+    if (rank < 0 || rank >= g.pdims[0] * g.pdims[1]) CD_INVALID_USAGE("rank out of range");
+    TransportTraits traits;
+    traits.pipelined = pipelined != 0;
+    traits.symmetric_recv = symmetric_recv != 0;
+    const CommAxis ca = (op == OP_X_TO_Y || op == OP_Y_TO_X) ? COMM_COL : COMM_ROW;
+    const int P = g.pdims[ca == COMM_COL ? 0 : 1];
+    const TransposePlan p = buildTransposePlan(g, rank, (TransposeOp)op, in_halo, out_halo, in_pad, out_pad, inplace,
+                                               traits, npergroup > 0 ? npergroup : P);
+    std::vector<int> members(P);
+    const auto pidx = gridIndexOfRank(g, rank);
+    for (int i = 0; i < P; ++i) members[i] = globalRankOf(g, pidx, ca, i);
+    exportTransposePlan(p, members, out);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtPlanHalo(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis, const int32_t halo[],
+                                     const bool periods[], int32_t dim, const int32_t pad[], int32_t force_packed,
+                                     cudecompExtHaloPlan_t* out) {
+  try {
+    const GridShape g = shapeFromSpec(grid);
+    if (!out || !halo) CD_INVALID_USAGE("null argument");
+    if (axis < 0 || axis > 2 || dim < 0 || dim > 2) CD_INVALID_USAGE("axis/dim out of range");
+    if (rank < 0 || rank >= g.pdims[0] * g.pdims[1]) CD_INVALID_USAGE("rank out of range");
+    const int32_t zero[3] = {0, 0, 0};
+    const bool none[3] = {false, false, false};
+    const HaloPlan p = buildHaloPlan(g, rank, axis, dim, halo, periods ? periods : none, pad ? pad : zero, force_packed != 0);
+    exportHaloPlan(p, out);
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {

@@ -62,6 +62,24 @@ cudecompResult_t cudecompExtGetHaloPlan(cudecompHandle_t handle, cudecompGridDes
                                         const int32_t halo_extents[], const bool halo_periods[], int32_t dim,
                                         const int32_t padding[], int32_t backend_override, cudecompExtHaloPlan_t* plan);
 
+/* Stateless planner: the plan rank `rank` of a `pdims[0] x pdims[1]` grid would run, computed without any
+ * communicator, handle or device -- one process can therefore build the plans of EVERY rank and execute the whole
+ * exchange on host arrays (tests/test_plan_sim.py drives this with randomly drawn decompositions).
+ * gdims_dist entries <= 0 mean "same as gdims"; mem_order rows must be permutations.  pipelined / symmetric_recv /
+ * npergroup are the transport traits the executor would pass (NCCL: 0/0, *_PL: 1/x, peer transport: x/1). */
+typedef struct {
+  int32_t gdims[3], gdims_dist[3], pdims[2], col_major;
+  int32_t mem_order[3][3]; /* [pencil axis][memory position] -> global axis */
+} cudecompExtGridSpec_t;
+cudecompResult_t cudecompExtPlanTranspose(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t op,
+                                          const int32_t input_halo_extents[], const int32_t output_halo_extents[],
+                                          const int32_t input_padding[], const int32_t output_padding[], bool inplace,
+                                          int32_t pipelined, int32_t symmetric_recv, int32_t npergroup,
+                                          cudecompExtTransposePlan_t* plan);
+cudecompResult_t cudecompExtPlanHalo(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis,
+                                     const int32_t halo_extents[], const bool halo_periods[], int32_t dim,
+                                     const int32_t padding[], int32_t force_packed, cudecompExtHaloPlan_t* plan);
+
 /* Averages over the last (up to 32) calls of one transpose op, recorded when CUDECOMP_ENABLE_PERFORMANCE_REPORT=1
  * was set at cudecompInit (0 calls otherwise).  Synchronises the device.  exchange_ms is the all-to-all
  * (including host-side ordering for the host-ordered transports); per-peer pipelined backends report the

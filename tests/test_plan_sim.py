@@ -1,0 +1,202 @@
+"""All ranks in ONE process: the product's planner (`cudecompExtPlanTranspose` / `cudecompExtPlanHalo`, the same
+`buildTransposePlan` / `buildHaloPlan` the executors use) is asked for the plan of every rank of a decomposition,
+the plans are executed on host arrays with numpy and the exchange is simulated by copying chunks between the ranks'
+buffers.  No GPU, no processes -- so hypothesis can draw hundreds of decompositions (ragged extents, uneven
+splits, gdims_dist, both rank orders, arbitrary memory orders, halos, padding, in place, every transport trait)
+and every one is checked against the reference's analytic oracle (interior of every output pencil for
+transposes, the whole pencil for halo updates) and the oracle's restatement of the reference algorithm."""
+import itertools
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+import cudecomp_amd as cd
+from oracle import oracle as orc
+from tests.bodies import run_moves
+
+PERMS = list(itertools.permutations((0, 1, 2)))
+KIND = 1  # fp64 payload: global indices are exact
+DT = orc.KINDS[KIND][0]
+
+
+@st.composite
+def decompositions(draw, max_ranks=12):
+    pdims = draw(st.sampled_from([(a, b) for a in range(1, 7) for b in range(1, 7) if a * b <= max_ranks]))
+    lo = max(pdims)  # no empty pencils: that case has its own test
+    gdims = tuple(draw(st.integers(lo, lo + 9)) for _ in range(3))
+    if draw(st.booleans()):
+        mem_order = tuple(draw(st.sampled_from(PERMS)) for _ in range(3))
+    else:
+        ac = tuple(draw(st.booleans()) for _ in range(3))
+        mem_order = tuple(tuple((ax + i) % 3 if ac[ax] else i for i in range(3)) for ax in range(3))
+    gdims_dist = None
+    if draw(st.booleans()):
+        gdims_dist = tuple(draw(st.integers(max(lo, g - 3), g)) for g in gdims)
+    return {"gdims": gdims, "pdims": pdims, "mem_order": mem_order, "gdims_dist": gdims_dist,
+            "col_major": draw(st.booleans())}
+
+
+small3 = st.tuples(st.integers(0, 2), st.integers(0, 2), st.integers(0, 2))
+
+
+def _grids(d):
+    spec = cd.make_grid_spec(d["gdims"], d["pdims"], d["mem_order"], d["gdims_dist"], d["col_major"])
+    g = orc.Grid(d["gdims"], d["pdims"], gdims_dist=d["gdims_dist"], rank_order=2 if d["col_major"] else 1,
+                 mem_order=d["mem_order"])
+    return spec, g
+
+
+def _regions_disjoint(a0, a1, b0, b1):
+    return a1 <= b0 or b1 <= a0 or a0 == a1 or b0 == b1
+
+
+def simulate_transpose(d, op, halos, pads, inplace, pipelined, symmetric, npergroup):
+    spec, g = _grids(d)
+    n = g.nranks
+    ai, ao = orc.OP_AXES[op]
+    pa = [g.pencil_info(r, ai, halos[0], pads[0]) for r in range(n)]
+    pb = [g.pencil_info(r, ao, halos[1], pads[1]) for r in range(n)]
+    wsz = g.transpose_workspace_size()
+    plans = [cd.cudecompExtPlanTranspose(spec, r, op, halos[0], halos[1], pads[0], pads[1], inplace, pipelined,
+                                         symmetric, npergroup) for r in range(n)]
+    bufs = []
+    for r in range(n):
+        nel = max(pa[r].size, pb[r].size)
+        a = np.full(nel, -7, dtype=DT)
+        a[:pa[r].size] = g.fill_pencil(pa[r], KIND)
+        b = a if inplace else np.full(nel, -9, dtype=DT)
+        bufs.append([a, b, np.full(wsz, -11, dtype=DT)])
+    for r in range(n):
+        if not plans[r].noop:
+            run_moves(plans[r].pack, plans[r].n_pack, bufs[r])
+    # the exchange: snapshot every chunk first (an all-to-all reads all sends before any receive is visible)
+    flights = []
+    for r in range(n):
+        p = plans[r]
+        if p.noop or not p.exchange:
+            continue
+        for di in range(p.nranks):
+            gr = p.member_global_rank[di]
+            q = plans[gr]
+            so, sc = p.send_base + p.send_off[di], p.send_cnt[di]
+            assert q.exchange and q.nranks == p.nranks and q.member_global_rank[p.comm_rank] == r
+            assert q.recv_cnt[p.comm_rank] == sc, "send / receive counts of a pair differ"
+            if symmetric:
+                assert p.remote_recv_off[di] == q.recv_off[p.comm_rank], "one-sided slot offset differs from the receiver's"
+            flights.append((gr, q.recv_buf, q.recv_base + q.recv_off[p.comm_rank], bufs[r][p.send_buf][so:so + sc].copy()))
+        # a rank's send and receive areas must not overlap when they live in the same buffer
+        if p.send_buf == p.recv_buf:
+            s0 = p.send_base + min(p.send_off[i] for i in range(p.nranks))
+            s1 = p.send_base + max(p.send_off[i] + p.send_cnt[i] for i in range(p.nranks))
+            r0 = p.recv_base + min(p.recv_off[i] for i in range(p.nranks))
+            r1 = p.recv_base + max(p.recv_off[i] + p.recv_cnt[i] for i in range(p.nranks))
+            assert _regions_disjoint(s0, s1, r0, r1), "send and receive areas overlap"
+    for gr, buf, off, data in flights:
+        assert off + data.size <= bufs[gr][buf].size, "receive chunk runs past the buffer"
+        bufs[gr][buf][off:off + data.size] = data
+    for r in range(n):
+        if not plans[r].noop:
+            run_moves(plans[r].unpack, plans[r].n_unpack, bufs[r])
+    for r in range(n):
+        got = np.ascontiguousarray(bufs[r][1][:pb[r].size])
+        exp = g.fill_pencil(pb[r], KIND)
+        bad = orc.compare_pencil(pb[r], KIND, exp, got, True)
+        assert bad == 0, "rank %d: output pencil wrong at element %d" % (r, bad - 1)
+
+
+@settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+@given(d=decompositions(), op=st.sampled_from(cd.OPS), in_halo=small3, out_halo=small3, in_pad=small3, out_pad=small3,
+       inplace=st.booleans(), pipelined=st.booleans(), symmetric=st.booleans(), grouped=st.booleans())
+def test_transpose_plans_random_decompositions(d, op, in_halo, out_halo, in_pad, out_pad, inplace, pipelined, symmetric,
+                                               grouped):
+    ai, ao = orc.OP_AXES[op]
+    # in place means ONE buffer holding both pencils, which the API only defines when both views describe it
+    # consistently; like the reference's tests, draw independent halos/padding for the two sides
+    P = d["pdims"][0] if op in ("XToY", "YToX") else d["pdims"][1]
+    npergroup = 0
+    if grouped and P > 1:
+        divisors = [k for k in range(1, P + 1) if P % k == 0]
+        npergroup = divisors[len(divisors) // 2]
+    simulate_transpose(d, op, (in_halo, out_halo), (in_pad, out_pad), inplace, pipelined, symmetric, npergroup)
+
+
+@settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck))
+@given(d=decompositions(max_ranks=8), inplace=st.booleans(), symmetric=st.booleans())
+def test_transpose_cycle_returns_the_input(d, inplace, symmetric):
+    zero = ((0, 0, 0), (0, 0, 0))
+    for op in cd.OPS:
+        simulate_transpose(d, op, zero, zero, inplace, False, symmetric, 0)
+
+
+def simulate_halos(d, axis, halo, periods, padding, force_packed):
+    """dims 0, 1, 2 in sequence (so edges and corners fill), compared with the oracle's restatement after every dim
+    and with the analytic reference at the end; returns False if the configuration is not supported."""
+    spec, g = _grids(d)
+    n = g.nranks
+    pin = [g.pencil_info(r, axis, halo, padding) for r in range(n)]
+    ws = max(max(g.halo_workspace_size(r, axis, halo) for r in range(n)), 1)
+    data = [g.fill_pencil(pin[r], KIND, halo_style=True) for r in range(n)]
+    ref = [a.copy() for a in data]
+    ref_work = [np.zeros(ws, dtype=DT) for _ in range(n)]
+    work = [np.full(ws, -13, dtype=DT) for _ in range(n)]
+    for dim in range(3):
+        rc = g.update_halos(axis, KIND, ref, ref_work, halo, periods, dim, padding)
+        try:
+            plans = [cd.cudecompExtPlanHalo(spec, r, axis, halo, periods, dim, padding, force_packed) for r in range(n)]
+        except cd.CudecompError as e:
+            assert rc != orc.OK and e.code == rc, "product refused (%d) what the oracle accepts (%d)" % (e.code, rc)
+            return False
+        assert rc == orc.OK, "oracle refused what the product accepts"
+        for r in range(n):
+            bufs = [data[r], data[r], work[r]]
+            if plans[r].kind != 0:
+                run_moves(plans[r].pre, plans[r].n_pre, bufs)
+        flights = []
+        for r in range(n):
+            p = plans[r]
+            if p.kind in (0, 1):
+                continue
+            src = [data[r], data[r], work[r]][p.xbuf]
+            for i in range(2):  # my low (0) / high (1) face goes to that neighbour's opposite receive slot
+                nb = p.neighbor[i]
+                if nb < 0:
+                    continue
+                q = plans[nb]
+                assert q.kind == p.kind and q.neighbor[1 - i] == r and q.face_elements == p.face_elements
+                flights.append((nb, q.xbuf, q.recv_off[1 - i], src[p.send_off[i]:p.send_off[i] + p.face_elements].copy()))
+        for nb, xbuf, off, face in flights:
+            dst = [data[nb], data[nb], work[nb]][xbuf]
+            dst[off:off + face.size] = face
+        for r in range(n):
+            if plans[r].kind != 0:
+                run_moves(plans[r].post, plans[r].n_post, [data[r], data[r], work[r]])
+        for r in range(n):
+            assert np.array_equal(data[r], ref[r]), "rank %d differs from the oracle after dim %d" % (r, dim)
+    for r in range(n):
+        assert np.array_equal(data[r], g.fill_halo_reference(pin[r], KIND, periods)), "rank %d: analytic halo check" % r
+    return True
+
+
+@settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+@given(d=decompositions(), axis=st.integers(0, 2), halo=small3, periods=st.tuples(st.booleans(), st.booleans(), st.booleans()),
+       padding=small3, force_packed=st.booleans())
+def test_halo_plans_random_decompositions(d, axis, halo, periods, padding, force_packed):
+    simulate_halos(d, axis, halo, periods, padding, force_packed)
+
+
+def test_halo_wider_than_the_neighbours_slab_is_refused_like_the_oracle():
+    d = {"gdims": (4, 4, 4), "pdims": (2, 2), "mem_order": ((0, 1, 2),) * 3, "gdims_dist": None, "col_major": False}
+    assert simulate_halos(d, 0, (0, 3, 0), (True, True, True), (0, 0, 0), False) is False
+    assert simulate_halos(d, 0, (0, 2, 0), (True, True, True), (0, 0, 0), False) is True
+
+
+def test_empty_pencils_are_not_supported():
+    spec = cd.make_grid_spec((3, 8, 8), (4, 1), ((0, 1, 2),) * 3)  # 3 planes over 4 ranks: one Y pencil is empty
+    with pytest.raises(cd.CudecompError) as e:
+        cd.cudecompExtPlanTranspose(spec, 0, "XToY")
+    assert e.value.code == 2  # CUDECOMP_RESULT_NOT_SUPPORTED
+    with pytest.raises(cd.CudecompError) as e:
+        cd.cudecompExtPlanHalo(spec, 0, 1, (1, 1, 1), (True, True, True), 0)
+    assert e.value.code == 2
