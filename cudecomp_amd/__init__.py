@@ -92,6 +92,11 @@ class ExtHaloPlan(C.Structure):
                 ("send_off", C.c_int64 * 2), ("recv_off", C.c_int64 * 2), ("pre", ExtMove * 2), ("post", ExtMove * 2)]
 
 
+class ExtCounters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("graphs_captured", "graph_launches", "local", "rccl", "mpi", "peer_barrier",
+                                          "peer_fused", "peer_pipelined")]
+
+
 class ExtGridSpec(C.Structure):
     _fields_ = [("gdims", C.c_int32 * 3), ("gdims_dist", C.c_int32 * 3), ("pdims", C.c_int32 * 2),
                 ("col_major", C.c_int32), ("mem_order", (C.c_int32 * 3) * 3)]
@@ -109,7 +114,7 @@ API_SYMBOLS = [
     "cudecompUpdateHalosY", "cudecompUpdateHalosZ",
 ]
 EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecompExtMove3D",
-               "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe", "cudecompExtGetGraphStats",
+               "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
                "cudecompExtPlanTranspose", "cudecompExtPlanHalo"]
 
 
@@ -175,7 +180,7 @@ def lib():
                                              C.POINTER(ExtHaloPlan)]
         L.cudecompExtGetTransposeTimings.argtypes = [vp, vp, i32, C.POINTER(ExtTransposeTimings)]
         L.cudecompExtPeerProbe.argtypes = [vp, vp, C.c_size_t, pi32]
-        L.cudecompExtGetGraphStats.argtypes = [vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cudecompExtGetCounters.argtypes = [vp, vp, C.POINTER(ExtCounters)]
         L.cudecompExtPlanTranspose.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, pi32, pi32, C.c_bool, i32,
                                                i32, i32, C.POINTER(ExtTransposePlan)]
         L.cudecompExtPlanHalo.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, C.POINTER(C.c_bool), i32, pi32, i32,
@@ -360,10 +365,11 @@ def cudecompExtPlanHalo(grid, rank, axis, halo_extents, halo_periods, dim, paddi
     return p
 
 
-def cudecompExtGetGraphStats(handle, gd):
-    captured, launches = C.c_int64(0), C.c_int64(0)
-    _check(lib().cudecompExtGetGraphStats(handle, gd, C.byref(captured), C.byref(launches)), "cudecompExtGetGraphStats")
-    return captured.value, launches.value
+def cudecompExtGetCounters(handle, gd):
+    """dict of executor-path counters of this descriptor (see cudecompExtCounters_t)."""
+    c = ExtCounters()
+    _check(lib().cudecompExtGetCounters(handle, gd, C.byref(c)), "cudecompExtGetCounters")
+    return {name: getattr(c, name) for name, _ in ExtCounters._fields_}
 
 
 def cudecompExtPeerProbe(handle, buffer, nbytes):

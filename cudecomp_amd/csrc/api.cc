@@ -238,6 +238,7 @@ void buildCommInfo(cudecompHandle_t h, cudecompGridDesc_t gd) {
     ci.barrier_slot = h->next_barrier_slot;
     h->next_barrier_slot = (h->next_barrier_slot + 1) % 64;
     ci.barrier_epoch = 0;
+    ci.pipeline_epoch = 0;
     peerResetBarrierSlot(h, ci.barrier_slot);
     ci.nranks = gd->shape.pdims[e.axis == COMM_ROW ? 1 : 0];
     ci.rank = gd->pidx[e.axis == COMM_ROW ? 1 : 0];
@@ -279,6 +280,7 @@ cudecompGridDesc::~cudecompGridDesc() {
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
   for (auto& kv : pack_graphs) (void)hipGraphExecDestroy(kv.second);
   if (graph_stream) (void)hipStreamDestroy(graph_stream);
+  if (entry_event) (void)hipEventDestroy(entry_event);
 }
 
 // ------------------------------------------------------------------------------------------------

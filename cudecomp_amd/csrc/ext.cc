@@ -219,14 +219,19 @@ cudecompResult_t cudecompExtPlanHalo(const cudecompExtGridSpec_t* grid, int32_t 
   return CUDECOMP_RESULT_SUCCESS;
 }
 
-cudecompResult_t cudecompExtGetGraphStats(cudecompHandle_t handle, cudecompGridDesc_t gd, int64_t* captured,
-                                          int64_t* launches) {
+cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDesc_t gd, cudecompExtCounters_t* out) {
   try {
     if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
     if (!gd || !gd->initialized || gd->handle != handle) CD_INVALID_USAGE("invalid grid descriptor");
-    if (!captured || !launches) CD_INVALID_USAGE("null argument");
-    *captured = (int64_t)gd->pack_graphs.size();
-    *launches = gd->graph_launches;
+    if (!out) CD_INVALID_USAGE("null argument");
+    out->graphs_captured = (int64_t)gd->pack_graphs.size();
+    out->graph_launches = gd->graph_launches;
+    out->local = gd->path_count[PATH_LOCAL];
+    out->rccl = gd->path_count[PATH_RCCL];
+    out->mpi = gd->path_count[PATH_MPI];
+    out->peer_barrier = gd->path_count[PATH_PEER_BARRIER];
+    out->peer_fused = gd->path_count[PATH_PEER_FUSED];
+    out->peer_pipelined = gd->path_count[PATH_PEER_PIPELINED];
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {

@@ -16,6 +16,7 @@
 #include "plan.h"
 
 namespace cudecomp {
+enum ExecPath { PATH_LOCAL = 0, PATH_RCCL, PATH_MPI, PATH_PEER_BARRIER, PATH_PEER_FUSED, PATH_PEER_PIPELINED };
 class RcclContext;  // transport.cc
 class PeerContext;  // transport.cc
 }  // namespace cudecomp
@@ -28,6 +29,7 @@ struct cudecompCommInfo {
   std::unique_ptr<cudecomp::Bootstrap> boot;  // control-plane communicator of the members
   int barrier_slot = -1;                      // row in the shared-memory barrier board (peer transport)
   uint64_t barrier_epoch = 0;
+  uint64_t pipeline_epoch = 0;                // pairwise-flag epoch of the pipelined peer exchange
 };
 
 struct cudecompHandle {
@@ -88,7 +90,9 @@ struct cudecompGridDesc {
   using PackGraphKey = std::tuple<TransposeKey, const void*, const void*, const void*, int>;
   std::map<PackGraphKey, hipGraphExec_t> pack_graphs;
   hipStream_t graph_stream = nullptr;
+  hipEvent_t entry_event = nullptr;  // pipelined peer exchange: "everything before this call" marker
   int64_t graph_launches = 0;
+  std::array<int64_t, 6> path_count{};  // transposes executed per path (cudecomp::ExecPath), for cudecompExtGetCounters
   bool graphs_failed = false;  // the runtime refused a capture: stay on plain launches
 
   // performance samples (CUDECOMP_ENABLE_PERFORMANCE_REPORT=1), one ring of event quadruples

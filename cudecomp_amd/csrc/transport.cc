@@ -82,6 +82,7 @@ class PeerContext {
     if (board_) ::munmap(board_, board_bytes_);
     for (auto& kv : regions_) closePeers(kv.second);
     for (hipStream_t s : copy_streams_) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : copy_events_) (void)hipEventDestroy(e);
   }
 
   Region* find(const void* ptr) {
@@ -189,9 +190,42 @@ class PeerContext {
 
   // a communicator slot is (re)initialised by its members BEFORE the collective that creates the communicator
   void resetSlot(int slot) {
-    if (board_ && slot >= 0) cell(slot, h_->rank).store(0, std::memory_order_release);
+    if (!board_ || slot < 0) return;
+    cell(slot, h_->rank).store(0, std::memory_order_release);
+    if (flags_) {
+      ready(slot, h_->rank).store(0, std::memory_order_release);
+      for (int s = 0; s < h_->nranks; ++s) landed(slot, h_->rank, s).store(0, std::memory_order_release);
+    }
   }
   bool hasBoard() const { return board_ != nullptr; }
+
+  // ---- pairwise flags of the pipelined exchange (same shared segment, behind the barrier cells) -----------
+  // ready(slot, r)      = last epoch for which rank r's receive area was free
+  // landed(slot, d, s)  = last epoch whose chunk from rank s has completely arrived in rank d's receive area
+  bool pipelineAvailable(const cudecompCommInfo& ci) const { return flags_ && ci.ngroups == 1 && ci.barrier_slot >= 0; }
+  std::atomic<uint64_t>& ready(int slot, int rank) { return flags_[((size_t)slot * h_->nranks + rank) * (h_->nranks + 1)]; }
+  std::atomic<uint64_t>& landed(int slot, int dst, int src) {
+    return flags_[((size_t)slot * h_->nranks + dst) * (h_->nranks + 1) + 1 + src];
+  }
+  void waitFlag(std::atomic<uint64_t>& f, uint64_t epoch, const char* what) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    int spins = 0;
+    while (f.load(std::memory_order_acquire) < epoch) {
+      if (++spins > 2000) {
+        std::this_thread::yield();
+        if ((spins & 0xfff) == 0 && std::chrono::steady_clock::now() > deadline)
+          CD_PEER_ERROR(std::string("timed out waiting for a peer in the pipelined exchange (") + what + ")");
+      }
+    }
+  }
+  hipEvent_t copyEvent(int i) {
+    while ((int)copy_events_.size() <= i) {
+      hipEvent_t e;
+      CD_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      copy_events_.push_back(e);
+    }
+    return copy_events_[i];
+  }
 
   hipStream_t copyStream(int i) {
     while ((int)copy_streams_.size() <= i) {
@@ -215,7 +249,11 @@ class PeerContext {
   void openBoard() {
     // every host gets its own segment; its name is agreed through the bootstrap, the creator unlinks it as
     // soon as all local ranks have mapped it, so nothing is left behind even if a rank crashes later
-    board_bytes_ = (size_t)kSlots * h_->nranks * 64;
+    const size_t cells_bytes = (size_t)kSlots * h_->nranks * 64;
+    // pairwise flags: (1 + nranks) counters per slot and rank; left out for very large worlds (the pipelined
+    // exchange then falls back to the barrier-ordered one)
+    const size_t flags_bytes = h_->nranks <= 32 ? (size_t)kSlots * h_->nranks * (h_->nranks + 1) * sizeof(uint64_t) : 0;
+    board_bytes_ = cells_bytes + flags_bytes;
     char name[128] = {0};
     if (h_->local_rank == 0)
       snprintf(name, sizeof(name), "/cudecomp_%d_%llx", (int)::getpid(),
@@ -241,13 +279,19 @@ class PeerContext {
     const bool ok = (p != MAP_FAILED);
     const bool all_ok = !h_->boot->allreduceOr(!ok);  // also: everybody has mapped it
     if (h_->local_rank == 0) ::shm_unlink(shm_name);
-    if (ok && all_ok) board_ = static_cast<char*>(p);
-    else if (ok) ::munmap(p, board_bytes_);  // fall back to bootstrap barriers everywhere
+    if (ok && all_ok) {
+      board_ = static_cast<char*>(p);
+      if (flags_bytes) flags_ = reinterpret_cast<std::atomic<uint64_t>*>(board_ + cells_bytes);
+    } else if (ok) {
+      ::munmap(p, board_bytes_);  // fall back to bootstrap barriers everywhere
+    }
   }
 
   cudecompHandle_t h_;
   std::map<char*, Region> regions_;
   std::vector<hipStream_t> copy_streams_;
+  std::vector<hipEvent_t> copy_events_;
+  std::atomic<uint64_t>* flags_ = nullptr;
   char* board_ = nullptr;
   size_t board_bytes_ = 0;
 };
@@ -438,6 +482,49 @@ void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePl
   launchMoves(moves.data(), (int)moves.size(), bufs, es, stream, &h->tuning, nullptr, dst_base.data());
   CD_CHECK_HIP(hipStreamSynchronize(stream));
   pc.barrier(ci);  // every chunk has landed everywhere
+}
+
+bool peerPipelineAvailable(cudecompHandle_t h, const cudecompCommInfo& ci) {
+  return h->peer && h->peer->pipelineAvailable(ci);
+}
+
+// Per-peer pipeline of the one-sided transport (NVSHMEM_PL / MPI_P2P_PL enums): chunk by chunk
+//   pack(d) [caller, event per destination] -> copy to d over xGMI [one stream per peer] -> d unpacks it
+// with pairwise flags in the shared board instead of communicator-wide barriers: a copy to d starts as soon as
+// d's receive area is free and d's chunk is packed, and the unpack of the chunk from s is launched as soon as s
+// reports it landed -- packs, the P-1 link transfers and unpacks overlap.  Host-driven like the other
+// host-ordered exchanges (returns when every incoming chunk has been handed to an unpack launch).
+void peerPipelinedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
+                           void* const bufs[3], const ExchangeBuffers& b, int es, hipEvent_t entry, hipStream_t stream) {
+  PeerContext& pc = *h->peer;
+  const int P = plan.nranks, me = plan.comm_rank, slot = ci.barrier_slot;
+  const uint64_t epoch = ++ci.pipeline_epoch;
+  std::vector<char*> remote(P, nullptr);  // registering a foreign receive buffer is collective: do it first
+  for (int d = 0; d < P; ++d) remote[d] = pc.translate(b.recv, ci.global_ranks[d]) + plan.remote_recv_off[d] * es;
+
+  // my receive area is free once everything that was on the stream before this call has completed
+  CD_CHECK_HIP(hipEventSynchronize(entry));
+  pc.ready(slot, h->rank).store(epoch, std::memory_order_release);
+
+  for (int j = 0; j < P; ++j) {
+    const int d = (j == 0) ? me : plan.schedule_dst[j];
+    hipStream_t cs = pc.copyStream(j);
+    CD_CHECK_HIP(hipStreamWaitEvent(cs, gd->events[d], 0));  // chunk for d is packed
+    if (d != me) pc.waitFlag(pc.ready(slot, ci.global_ranks[d]), epoch, "receive area of the destination");
+    if (plan.send_cnt[d])
+      CD_CHECK_HIP(hipMemcpyAsync(remote[d], b.send + plan.send_off[d] * es, (size_t)plan.send_cnt[d] * es,
+                                  hipMemcpyDeviceToDevice, cs));
+    CD_CHECK_HIP(hipEventRecord(pc.copyEvent(j), cs));
+  }
+  for (int j = 0; j < P; ++j) {
+    const int d = (j == 0) ? me : plan.schedule_dst[j];
+    const int s = (j == 0) ? me : plan.schedule_src[j];
+    CD_CHECK_HIP(hipEventSynchronize(pc.copyEvent(j)));  // my chunk for d has landed
+    pc.landed(slot, ci.global_ranks[d], h->rank).store(epoch, std::memory_order_release);
+    if (s != me) pc.waitFlag(pc.landed(slot, h->rank, ci.global_ranks[s]), epoch, "chunk from the source");
+    for (const Move3D& m : plan.unpack)
+      if (m.peer == s) launchMoves(&m, 1, bufs, es, stream, &h->tuning);
+  }
 }
 
 void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t, cudecompCommInfo& ci, const TransposePlan& plan,

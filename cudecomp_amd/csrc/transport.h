@@ -53,6 +53,12 @@ void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInf
 void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, void* const bufs[3], int es,
                      hipStream_t stream);
 
+// Per-peer pipeline of the one-sided transport.  Preconditions: `entry` was recorded on `stream` before the pack
+// kernels of this call, and gd->events[d] after the pack kernel of destination d.  Launches the unpack moves itself.
+bool peerPipelineAvailable(cudecompHandle_t h, const cudecompCommInfo& ci);
+void peerPipelinedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
+                           void* const bufs[3], const ExchangeBuffers& b, int es, hipEvent_t entry, hipStream_t stream);
+
 // Per-peer variant used by the pipelined backends: exchange with the given members only.  Waits for
 // pack_done[dst] before sending to dst and makes `stream` wait for the arrival of each chunk.
 void alltoallExchangePeers(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,

@@ -69,6 +69,17 @@ hipGraphExec_t capturePackLoop(cudecompHandle_t h, cudecompGridDesc_t gd, const 
   return exec;
 }
 
+// which transport carries an exchange that is neither fused nor the pairwise-flag pipeline
+ExecPath exchangePath(cudecompHandle_t h, cudecompCommInfo& ci, cudecompTransposeCommBackend_t backend) {
+  if (transposeBackendIsRccl(backend)) return PATH_RCCL;
+#ifdef CUDECOMP_WITH_MPI
+  if (transposeBackendIsMpi(backend) && mpiTransportAvailable(ci)) return PATH_MPI;
+#endif
+  (void)h;
+  (void)ci;
+  return PATH_PEER_BARRIER;
+}
+
 }  // namespace
 
 void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, void* input, void* output, void* work,
@@ -107,6 +118,7 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
   hipEvent_t* pev = perfBeginTranspose(h, gd, (int)op, dtype, hp, inplace, plan.exchange ? plan.pencil_elements_a * es : 0, stream);
 
   if (!plan.exchange) {
+    gd->path_count[PATH_LOCAL]++;
     launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
     perfMark(pev, 1, stream);
     perfMark(pev, 2, stream);
@@ -122,6 +134,7 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
 
   if (backend == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_SM) {
     // compute-unit driven: pack straight into the peers' receive areas
+    gd->path_count[PATH_PEER_FUSED]++;
     perfMark(pev, 1, stream);  // pack and exchange are one fused phase here: all of it counts as exchange
     peerPutExchange(h, ci, plan, bufs, es, stream);
     perfMark(pev, 2, stream);
@@ -130,6 +143,7 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
     return;
   }
   if (!traits.pipelined) {
+    gd->path_count[exchangePath(h, ci, backend)]++;
     launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
     perfMark(pev, 1, stream);
     alltoallExchange(h, gd, ci, plan, xb, es, backend, stream);
@@ -149,6 +163,12 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
       CD_CHECK_HIP(hipEventCreateWithFlags(&gd->events[i], hipEventDisableTiming));
   }
   perfMark(pev, 1, stream);
+  // one-sided transport with pairwise flags available: packs, link transfers and unpacks overlap chunk by chunk
+  const bool peer_pipeline = usesPeerTransport(h, backend) && peerPipelineAvailable(h, ci);
+  if (peer_pipeline) {
+    if (!gd->entry_event) CD_CHECK_HIP(hipEventCreateWithFlags(&gd->entry_event, hipEventDisableTiming));
+    CD_CHECK_HIP(hipEventRecord(gd->entry_event, stream));
+  }
   if (!plan.pack.empty()) {
     // With graphs enabled the loop is captured once on a private stream -- each destination's kernel followed by an
     // event-record NODE hanging off it, so the side stream can wait on the per-peer events after the launch --
@@ -176,6 +196,14 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
   } else {
     for (int d = 0; d < P; ++d) CD_CHECK_HIP(hipEventRecord(gd->events[d], stream));
   }
+  if (peer_pipeline) {
+    gd->path_count[PATH_PEER_PIPELINED]++;
+    peerPipelinedExchange(h, gd, ci, plan, bufs, xb, es, gd->entry_event, stream);
+    perfMark(pev, 2, stream);
+    perfMark(pev, 3, stream);
+    return;
+  }
+  gd->path_count[exchangePath(h, ci, backend)]++;
   for (int j = 0; j < P; ++j) {
     const int src = (j == 0) ? plan.comm_rank : plan.schedule_src[j];
     const int dst = (j == 0) ? plan.comm_rank : plan.schedule_dst[j];

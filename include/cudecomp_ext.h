@@ -97,10 +97,16 @@ cudecompResult_t cudecompExtGetTransposeTimings(cudecompHandle_t handle, cudecom
  * previous rank wrote into its own.  *mismatches = number of wrong blocks (0 = the IPC mapping is sound). */
 cudecompResult_t cudecompExtPeerProbe(cudecompHandle_t handle, void* buffer, size_t bytes, int32_t* mismatches);
 
-/* Graph statistics of a descriptor (CUDECOMP_ENABLE_CUDA_GRAPHS=1): number of distinct pack loops captured and
- * number of graph launches issued so far (captures included).  Both stay 0 when graphs are off or were refused. */
-cudecompResult_t cudecompExtGetGraphStats(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int64_t* captured,
-                                          int64_t* launches);
+/* Which executor paths a descriptor's transposes have taken so far (tests assert that the intended path ran):
+ * graphs_captured / graph_launches -- CUDECOMP_ENABLE_CUDA_GRAPHS: distinct pack loops captured, graph launches;
+ * local -- no exchange; rccl, mpi -- those transports; peer_barrier -- barrier-ordered one-sided exchange;
+ * peer_fused -- fused pack+put (NVSHMEM_SM); peer_pipelined -- per-peer pipeline with pairwise flags. */
+typedef struct {
+  int64_t graphs_captured, graph_launches;
+  int64_t local, rccl, mpi, peer_barrier, peer_fused, peer_pipelined;
+} cudecompExtCounters_t;
+cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
+                                        cudecompExtCounters_t* counters);
 
 /* Run one block move on the GPU (src/dst are device pointers, strides in elements of es bytes).
  * force_generic is a bit mask: 1 selects the element-wise fallback kernel, 2 forces the streaming

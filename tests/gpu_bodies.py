@@ -331,7 +331,7 @@ def repeated_cycle(rank, nranks, args):
                 failures.append("rank %d iteration %d %s: mismatch at %d" % (rank, it, op, bad - 1))
             cur.fill_(0xA5)  # a stale replay that re-read the old input would show up in the next hop
             cur, nxt = nxt, cur
-    graphs = cd.cudecompExtGetGraphStats(h, gd)
+    counters = cd.cudecompExtGetCounters(h, gd)
     cd.cudecompFree(h, gd, work)
     cd.cudecompGridDescDestroy(h, gd)
-    return {"failures": failures, "graphs": graphs}
+    return {"failures": failures, "counters": counters}

@@ -26,6 +26,9 @@ def test_pipelined_pack_loop_graph_replay(n, pdims, backend):
                 "iterations": 3}
         for r in run_ranks(n, "tests.gpu_bodies", "repeated_cycle", args, timeout=300, extra_env=env):
             assert r["failures"] == []
-            captured, launches = r["graphs"]
+            c = r["counters"]
             # every op whose pack phase addresses more than one destination captured once and launched 3 times
-            assert captured >= 1 and launches == 3 * captured, r["graphs"]
+            assert c["graphs_captured"] >= 1 and c["graph_launches"] == 3 * c["graphs_captured"], c
+            # and the exchanges went through the intended transport: pairwise-flag pipeline / the RCCL code path
+            exchanged = c["peer_pipelined"] + c["rccl"] + c["peer_barrier"] + c["peer_fused"] + c["mpi"]
+            assert exchanged > 0 and exchanged == (c["rccl"] if backend == cd.TRANSPOSE_COMM_NCCL_PL else c["peer_pipelined"]), c
