@@ -48,6 +48,8 @@ struct DevMove {
 
 struct Batch {
   int n;
+  int interleave;  // 1: workgroup b serves move b % n (moves with REMOTE destinations: keeps every xGMI link busy
+                   // for the whole launch instead of draining one peer's chunk after the other)
   int p0[kMaxBatch];                      // kernel-specific small parameter
   int p1[kMaxBatch];                      // second small parameter (transpose: XCD-contiguous tile walk)
   unsigned int first_block[kMaxBatch + 1];
@@ -122,6 +124,18 @@ __device__ __forceinline__ int findMove(const Batch& b, unsigned int block) {
   return mi;
 }
 
+// workgroup -> (move, workgroup index inside the move); false for the filler workgroups of an interleaved launch
+__device__ __forceinline__ bool locate(const Batch& b, unsigned int block, int& mi, unsigned int& lb) {
+  if (b.interleave) {
+    mi = (int)(block % (unsigned int)b.n);
+    lb = block / (unsigned int)b.n;
+    return lb < b.first_block[mi + 1] - b.first_block[mi];
+  }
+  mi = findMove(b, block);
+  lb = block - b.first_block[mi];
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // rows_kernel: e[0] = vectors per row, e[1] = rows, e[2] = planes; ss/ds[1], [2] in BYTES.
 // p0 = log2(lanes per row).  A workgroup covers (256 >> p0) * kRowsUnroll rows x (1 << p0) vectors.
@@ -129,9 +143,10 @@ __device__ __forceinline__ int findMove(const Batch& b, unsigned int block) {
 template <int VB, bool STREAM>
 __global__ __launch_bounds__(kThreads) void rows_kernel(const Batch b) {
   using V = Bytes<VB>;
-  const int mi = findMove(b, blockIdx.x);
+  int mi;
+  unsigned int lb;
+  if (!locate(b, blockIdx.x, mi, lb)) return;
   const DevMove& m = b.m[mi];
-  const unsigned int lb = blockIdx.x - b.first_block[mi];
   const int lg = b.p0[mi];
   const int lpr = 1 << lg;
   const int rb = kThreads >> lg;
@@ -224,9 +239,10 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
 
   __shared__ E tile[TJ * PITCH];
 
-  const int mi = findMove(b, blockIdx.x);
+  int mi;
+  unsigned int lb;
+  if (!locate(b, blockIdx.x, mi, lb)) return;
   const DevMove& m = b.m[mi];
-  const unsigned int lb = blockIdx.x - b.first_block[mi];
   const unsigned int ti_n = b.t0[mi], tj_n = b.t1[mi];
   // Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Give every XCD a
   // contiguous run of tiles, walked along i first: neighbouring tiles then extend the same source rows
@@ -276,9 +292,10 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
 template <int ES>
 __global__ __launch_bounds__(kThreads) void generic_kernel(const Batch b) {
   using E = Bytes<ES>;
-  const int mi = findMove(b, blockIdx.x);
+  int mi;
+  unsigned int lb;
+  if (!locate(b, blockIdx.x, mi, lb)) return;
   const DevMove& m = b.m[mi];
-  const unsigned int lb = blockIdx.x - b.first_block[mi];
   const unsigned int nb = b.first_block[mi + 1] - b.first_block[mi];
   const int f = b.p0[mi], g = (f + 1) % 3, h = (f + 2) % 3;
   const unsigned long long ef = m.e[f], eg = m.e[g];
@@ -487,6 +504,14 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
       done[j] = true;
     }
     b.first_block[b.n] = (unsigned int)blocks;
+    if (dst_base_override && b.n > 1) {
+      unsigned long long widest = 0;
+      for (int k = 0; k < b.n; ++k) widest = std::max<unsigned long long>(widest, b.first_block[k + 1] - b.first_block[k]);
+      if (widest * b.n <= 0x7fffffffULL) {
+        b.interleave = 1;
+        blocks = widest * b.n;
+      }
+    }
     launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, es, b, (unsigned int)blocks, stream);
     if (stats) stats->launches[cs[i].cls] += 1;
   }
