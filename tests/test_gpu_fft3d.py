@@ -29,3 +29,19 @@ def test_fft3d_four_ranks_peer_transport(pr, pc, extra):
                                "--backend", "8", "--warmup", "1", "--trials", "2"] + extra)
     assert rec["ok"], rec
     assert rec["pdims"] == [pr, pc]
+
+
+@pytest.mark.parametrize("nranks,args", [(1, ["--n", "48"]), (1, ["--n", "32", "--default-layout"]),
+                                         (4, ["--n", "48", "--pr", "2", "--pc", "2", "--backend", "1"]),
+                                         (4, ["--n", "40", "--pr", "1", "--pc", "4", "--backend", "8", "--default-layout"])])
+def test_poisson_example(nranks, args):
+    """examples/cc/poisson: spectral Poisson solve (FFT -> divide by -|k|^2 on the Z pencils -> inverse FFT) against the
+    analytic solution; exercises in-place complex128 transposes from a solver's point of view."""
+    import json
+    import subprocess
+
+    from tests.mp import run_binary_ranks
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples", "cc"), "poisson"])
+    logs = run_binary_ranks(nranks, [os.path.join(ROOT, "examples", "cc", "poisson")] + args)
+    recs = [json.loads(line) for text in logs for line in text.splitlines() if line.startswith("{")]
+    assert len(recs) == nranks and all(r["ok"] and r["max_abs_err"] < 1e-11 for r in recs), recs
