@@ -268,7 +268,7 @@ def main():
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": measured_traffic(args.layout) if n == 1024 else None,
-                    "kernel": "transpose_kernel<8,2,64,64,2>" if args.layout == "contiguous" else "rows_kernel<16,true>",
+                    "kernel": "transpose_kernel<8,2,64,64,2,true>" if args.layout == "contiguous" else "rows_kernel<16,true>",
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4)}
         out = {
             "metric": "transpose cycle (X->Y->Z->Y->X) effective bandwidth, %d^3 fp64" % n,

@@ -24,6 +24,7 @@ struct KernelTuning {
   bool no_streaming = false;    // never use non-temporal access (CUDECOMP_DISABLE_STREAMING_ACCESS=1)
   bool force_streaming = false; // tests: non-temporal access regardless of the move size
   int stream_alignment = 0;        // tuning aid: alignment (bytes) below which transposes use cached access (0 = 128)
+  int lds_swizzle = -1;            // tuning aid: LDS tile layout of the transposes (1 swizzled, 0 padded, -1 per element size)
   int walk_order = -1;             // tuning aid: transposes walk tiles i first (0) / j first (1); -1 = by strides
   int misaligned_store_mode = -1;  // tuning aid: streaming mode (0/1/2) for transposes with unaligned destination rows
 };

@@ -175,8 +175,76 @@ __global__ __launch_bounds__(kThreads) void rows_kernel(const Batch b) {
   }
 }
 
+// LDS tile layout: row r (a source row, TI elements along i) is stored without padding; inside the row the
+// VW-element groups (16 bytes for the vector variants) are permuted by XOR with the row's group index,
+//   position(r, c) = r * TI + (((c / VW) ^ ((r / VW) % G)) * VW + c % VW),   G = TI / VW.
+// Both phases then move whole 16-byte groups: the load phase writes the group it fetched, the store phase reads
+// the VW x VW block (rows lj..lj+VW-1, one group) with VW vector reads, transposes it in registers and emits VW
+// destination rows.  Lanes of a wavefront that work on the same group column sit in different rows and therefore,
+// after the XOR, in different groups: every LDS access is a conflict-free 16-byte one (the previous padded
+// layout spent half of its LDS cycles on bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.5).
 template <int ES, int VW, int TI, int TJ, int STREAM, bool GUARD>
 __device__ __forceinline__ void transposeTile(Bytes<ES>* tile, const Bytes<ES>* __restrict__ src,
+                                              Bytes<ES>* __restrict__ dst, long long i0, long long j0, long long ei,
+                                              long long ej, long long sj, long long di, int tid) {
+  using E = Bytes<ES>;
+  using V = Bytes<ES * VW>;
+  constexpr int G = TI / VW;            // groups per LDS row
+  constexpr int TPR = TI / VW;          // lanes per source row segment
+  constexpr int RPP = kThreads / TPR;   // source rows per pass
+  constexpr int NP = TJ / RPP;          // load passes
+  constexpr int TPO = TJ / VW;          // lanes per destination row segment
+  constexpr int BPO = kThreads / TPO;   // VW-row blocks of destination rows per pass
+  constexpr int NPO = TI / (BPO * VW);  // store passes
+  static_assert(TI == TJ, "the swizzle assumes square tiles");
+  V* vtile = reinterpret_cast<V*>(tile);
+  // ---- global -> registers (all loads issued before the first use) -> LDS, rows along i
+  {
+    const int lg = tid % TPR;  // group index inside the row
+    const int li = lg * VW;
+    const int lj = tid / TPR;
+    const E* base = src + (j0 + lj) * sj + i0 + li;
+    V regs[NP] = {};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (!GUARD || (i0 + li < ei && j0 + lj + p * RPP < ej))
+        regs[p] = loadVec<(STREAM >= 1), ES * VW>(base + (long long)(p * RPP) * sj);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = lj + p * RPP;
+      vtile[r * G + (lg ^ ((r / VW) % G))] = regs[p];
+    }
+  }
+  __syncthreads();
+  // ---- LDS -> registers (VW x VW block, transposed) -> global, rows along j
+  {
+    const int ljg = tid % TPO;  // group index along j: rows ljg*VW .. +VW-1 of the tile
+    const int lj = ljg * VW;
+    const int lb = tid / TPO;
+#pragma unroll
+    for (int p = 0; p < NPO; ++p) {
+      const int ig = lb + p * BPO;  // group along i: destination rows ig*VW .. +VW-1
+      V in[VW];
+#pragma unroll
+      for (int v = 0; v < VW; ++v) in[v] = vtile[(lj + v) * G + (ig ^ (ljg % G))];
+#pragma unroll
+      for (int a = 0; a < VW; ++a) {
+        V out;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) Lane<ES, VW>::set(out, v, Lane<ES, VW>::get(in[v], a));
+        const int ii = ig * VW + a;
+        if (!GUARD || (i0 + ii < ei && j0 + lj < ej))
+          storeVec<(STREAM >= 2), ES * VW>(dst + (i0 + ii) * di + j0 + lj, out);
+      }
+    }
+  }
+}
+
+// The padded layout (row pitch TI + 1 elements, element-wise LDS access): kept for 16-byte elements, where it is
+// already conflict-free and measures faster than the swizzled one.
+template <int ES, int VW, int TI, int TJ, int STREAM, bool GUARD>
+__device__ __forceinline__ void transposeTilePadded(Bytes<ES>* tile, const Bytes<ES>* __restrict__ src,
                                               Bytes<ES>* __restrict__ dst, long long i0, long long j0, long long ei,
                                               long long ej, long long sj, long long di, int tid) {
   using E = Bytes<ES>;
@@ -229,15 +297,15 @@ __device__ __forceinline__ void transposeTile(Bytes<ES>* tile, const Bytes<ES>* 
 // destination, k is the batch dim.  e = {ei, ej, ek}; ss = {1, sj, sk}; ds = {di, 1, dk} (elements).
 // ---------------------------------------------------------------------------------------------
 // STREAM: 0 = default caching, 1 = non-temporal loads, 2 = non-temporal loads and stores
-template <int ES, int VW, int TI, int TJ, int STREAM>
+template <int ES, int VW, int TI, int TJ, int STREAM, bool SWZ>
 __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
   using E = Bytes<ES>;
-  constexpr int PITCH = TI + 1;  // LDS row pitch in elements: +1 keeps column reads <= 2-way conflicted
   static_assert(TI % VW == 0 && TJ % VW == 0, "tile must hold whole vectors");
   static_assert(kThreads % (TI / VW) == 0 && TJ % (kThreads / (TI / VW)) == 0, "load mapping");
-  static_assert(kThreads % (TJ / VW) == 0 && TI % (kThreads / (TJ / VW)) == 0, "store mapping");
+  static_assert(kThreads % (TJ / VW) == 0 && TI % (kThreads / (TJ / VW) * VW) == 0, "store mapping");
 
-  __shared__ E tile[TJ * PITCH];
+  // XOR-swizzled without padding (transposeTile) or padded by one element per row (transposeTilePadded)
+  __shared__ __attribute__((aligned(16))) E tile[SWZ ? TJ * TI : TJ * (TI + 1)];
 
   int mi;
   unsigned int lb;
@@ -279,10 +347,12 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
 
   // interior tiles skip every bounds test, which lets the compiler batch the 8 loads, the LDS traffic and
   // the 8 stores of a lane; edge tiles take the guarded copy of the same code
-  if (i0 + TI <= ei && j0 + TJ <= ej) {
-    transposeTile<ES, VW, TI, TJ, STREAM, false>(tile, src, dst, i0, j0, ei, ej, sj, di, tid);
+  if constexpr (SWZ) {
+    if (i0 + TI <= ei && j0 + TJ <= ej) transposeTile<ES, VW, TI, TJ, STREAM, false>(tile, src, dst, i0, j0, ei, ej, sj, di, tid);
+    else transposeTile<ES, VW, TI, TJ, STREAM, true>(tile, src, dst, i0, j0, ei, ej, sj, di, tid);
   } else {
-    transposeTile<ES, VW, TI, TJ, STREAM, true>(tile, src, dst, i0, j0, ei, ej, sj, di, tid);
+    if (i0 + TI <= ei && j0 + TJ <= ej) transposeTilePadded<ES, VW, TI, TJ, STREAM, false>(tile, src, dst, i0, j0, ei, ej, sj, di, tid);
+    else transposeTilePadded<ES, VW, TI, TJ, STREAM, true>(tile, src, dst, i0, j0, ei, ej, sj, di, tid);
   }
 }
 
@@ -319,6 +389,7 @@ struct Classified {
   DevMove dm;
   int p0, p1;
   int stream;  // 0 default caching, 1 streaming loads, 2 streaming loads + stores
+  bool swizzle = false;  // transposes: XOR-swizzled LDS tile (else padded rows)
   unsigned int t0, t1;
   unsigned long long blocks;
   i64 elements;
@@ -389,6 +460,7 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     if (c.dm.e[0] % vw != 0 || c.dm.e[1] % vw != 0) vw = 1;
     c.variant = vw;
     c.p1 = 1;  // XCD-contiguous tile walk
+    c.swizzle = (tuning && tuning->lds_swizzle >= 0) ? tuning->lds_swizzle != 0 : es != 16;
     // Tile walk order inside an XCD's run: j first makes consecutive tiles extend the same DESTINATION rows
     // (contiguous write stream per row), i first the same source rows.  Measured on 8 GiB permutations
     // (profiles/r01_tuning.md): j first wins or ties for line-aligned moves (8-11 % at 16-byte elements and on
@@ -432,7 +504,7 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
   return c;
 }
 
-template <int STREAM>
+template <int STREAM, bool SWZ>
 void launchBatchT(MoveClass cls, int variant, int es, const Batch& b, unsigned int blocks, hipStream_t stream) {
   const dim3 grid(blocks), block(kThreads);
   constexpr bool ROWS_STREAM = STREAM >= 1;
@@ -444,13 +516,13 @@ void launchBatchT(MoveClass cls, int variant, int es, const Batch& b, unsigned i
       break;
     case MOVE_TRANSPOSE:
       if (es == 4) {
-        if (variant == 4) transpose_kernel<4, 4, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
-        else transpose_kernel<4, 1, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
+        if (variant == 4) transpose_kernel<4, 4, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
+        else transpose_kernel<4, 1, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
       } else if (es == 8) {
-        if (variant == 2) transpose_kernel<8, 2, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
-        else transpose_kernel<8, 1, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
+        if (variant == 2) transpose_kernel<8, 2, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
+        else transpose_kernel<8, 1, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
       } else {
-        transpose_kernel<16, 1, 32, 32, STREAM><<<grid, block, 0, stream>>>(b);
+        transpose_kernel<16, 1, 32, 32, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
       }
       break;
     default:
@@ -462,11 +534,17 @@ void launchBatchT(MoveClass cls, int variant, int es, const Batch& b, unsigned i
   CD_CHECK_HIP(hipGetLastError());
 }
 
-void launchBatch(MoveClass cls, int variant, int stream_access, int es, const Batch& b, unsigned int blocks,
-                 hipStream_t stream) {
-  if (stream_access == 2) launchBatchT<2>(cls, variant, es, b, blocks, stream);
-  else if (stream_access == 1) launchBatchT<1>(cls, variant, es, b, blocks, stream);
-  else launchBatchT<0>(cls, variant, es, b, blocks, stream);
+void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, int es, const Batch& b,
+                 unsigned int blocks, hipStream_t stream) {
+  if (swizzle) {
+    if (stream_access == 2) launchBatchT<2, true>(cls, variant, es, b, blocks, stream);
+    else if (stream_access == 1) launchBatchT<1, true>(cls, variant, es, b, blocks, stream);
+    else launchBatchT<0, true>(cls, variant, es, b, blocks, stream);
+  } else {
+    if (stream_access == 2) launchBatchT<2, false>(cls, variant, es, b, blocks, stream);
+    else if (stream_access == 1) launchBatchT<1, false>(cls, variant, es, b, blocks, stream);
+    else launchBatchT<0, false>(cls, variant, es, b, blocks, stream);
+  }
 }
 
 }  // namespace
@@ -487,7 +565,9 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
     Batch b{};
     unsigned long long blocks = 0;
     for (size_t j = i; j < cs.size() && b.n < kMaxBatch; ++j) {
-      if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant || cs[j].stream != cs[i].stream) continue;
+      if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant || cs[j].stream != cs[i].stream ||
+          cs[j].swizzle != cs[i].swizzle)
+        continue;
       if (blocks + cs[j].blocks > 0x7fffffffULL) {
         if (b.n == 0) CD_NOT_SUPPORTED("single block move too large for one launch");
         break;
@@ -512,7 +592,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
         blocks = widest * b.n;
       }
     }
-    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, es, b, (unsigned int)blocks, stream);
+    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, cs[i].swizzle, es, b, (unsigned int)blocks, stream);
     if (stats) stats->launches[cs[i].cls] += 1;
   }
 }

@@ -101,12 +101,12 @@ int main() {
         float ms = timeMove(k.m, src, dst, c.es);
         printf(" | auto: %7.3f ms %6.0f GB/s", ms, b / ms / 1e6);
       }
-      for (int al : {512, 4096}) {
-        g_tuning.stream_alignment = al;
+      for (int sw : {0, 1}) {
+        g_tuning.lds_swizzle = sw;
         float ms = timeMove(k.m, src, dst, c.es);
-        printf(" | cached unless %d-aligned: %7.3f ms", al, ms);
+        printf(" | %s LDS: %7.3f ms", sw ? "swizzled" : "padded", ms);
       }
-      g_tuning.stream_alignment = 0;
+      g_tuning.lds_swizzle = -1;
       printf("\n");
     }
   }
