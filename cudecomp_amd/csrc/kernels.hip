@@ -196,7 +196,6 @@ __device__ __forceinline__ void transposeTile(Bytes<ES>* tile, const Bytes<ES>* 
   constexpr int TPO = TJ / VW;          // lanes per destination row segment
   constexpr int BPO = kThreads / TPO;   // VW-row blocks of destination rows per pass
   constexpr int NPO = TI / (BPO * VW);  // store passes
-  static_assert(TI == TJ, "the swizzle assumes square tiles");
   V* vtile = reinterpret_cast<V*>(tile);
   // ---- global -> registers (all loads issued before the first use) -> LDS, rows along i
   {
