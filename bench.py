@@ -146,112 +146,133 @@ def main():
         os.environ["CUDECOMP_PERFORMANCE_REPORT_WARMUP_SAMPLES"] = str(args.warmup)
         os.environ["CUDECOMP_PERFORMANCE_REPORT_SAMPLES"] = str(max(args.steps, 1))
     h = cd.cudecompInit()
-    autotuned = None
-    if world == 1:
-        pdims = (1, 1)
-        cfg = cd.make_config((n, n, n), pdims, axis_contiguous=ac,
-                             transpose_backend=backends.get(args.backend, cd.TRANSPOSE_COMM_NCCL))
-        gd = cd.cudecompGridDescCreate(h, cfg)
-    else:
-        # BASELINE config 3: "autotuned pgrid".  The library's own autotuner (cudecompGridDescCreate with options)
-        # times every process grid x transport through the public transposes and keeps the fastest; a transport that
-        # cannot run on this system is dropped by the sweep.  --pdims / --backend pin either choice.
-        cfg = cd.make_config((n, n, n), tuple(args.pdims) if args.pdims else (0, 0), axis_contiguous=ac,
-                             transpose_backend=backends.get(args.backend, cd.TRANSPOSE_COMM_NCCL))
-        opt = cd.cudecompGridDescAutotuneOptionsSetDefaults()
-        opt.dtype = cd.DOUBLE
-        opt.n_warmup_trials, opt.n_trials = 2, 3
-        opt.autotune_transpose_backend = (args.backend == "auto")
-        for i in range(4):
-            opt.transpose_use_inplace_buffers[i] = bool(args.inplace)
-        if args.backend == "auto" or not args.pdims:
-            with c_stdout_to_stderr():  # the sweep logs "CUDECOMP: ..." lines on stdout; keep ours a single JSON line
-                gd = cd.cudecompGridDescCreate(h, cfg, opt)
-            autotuned = {"pdims": args.pdims is None, "backend": args.backend == "auto"}
-        else:
+    pin_backend, pin_pdims, fallback = args.backend, args.pdims, None
+    for attempt in (0, 1):
+        autotuned = None
+        if world == 1:
+            pdims = (1, 1)
+            cfg = cd.make_config((n, n, n), pdims, axis_contiguous=ac,
+                                 transpose_backend=backends.get(args.backend, cd.TRANSPOSE_COMM_NCCL))
             gd = cd.cudecompGridDescCreate(h, cfg)
-        pdims = (cfg.pdims[0], cfg.pdims[1])
-    used = names.get(cfg.transpose_comm_backend, cd.cudecompTransposeCommBackendToString(cfg.transpose_comm_backend))
+        else:
+            # BASELINE config 3: "autotuned pgrid".  The library's own autotuner (cudecompGridDescCreate with options)
+            # times every process grid x transport through the public transposes and keeps the fastest; a transport that
+            # cannot run on this system is dropped by the sweep.  --pdims / --backend pin either choice.
+            cfg = cd.make_config((n, n, n), tuple(pin_pdims) if pin_pdims else (0, 0), axis_contiguous=ac,
+                                 transpose_backend=backends.get(pin_backend, cd.TRANSPOSE_COMM_NCCL))
+            opt = cd.cudecompGridDescAutotuneOptionsSetDefaults()
+            opt.dtype = cd.DOUBLE
+            opt.n_warmup_trials, opt.n_trials = 2, 3
+            opt.autotune_transpose_backend = (pin_backend == "auto")
+            for i in range(4):
+                opt.transpose_use_inplace_buffers[i] = bool(args.inplace)
+            if pin_backend == "auto" or not pin_pdims:
+                with c_stdout_to_stderr():  # the sweep logs "CUDECOMP: ..." lines on stdout; keep ours a single JSON line
+                    gd = cd.cudecompGridDescCreate(h, cfg, opt)
+                autotuned = {"pdims": pin_pdims is None, "backend": pin_backend == "auto"}
+            else:
+                gd = cd.cudecompGridDescCreate(h, cfg)
+            pdims = (cfg.pdims[0], cfg.pdims[1])
+        used = names.get(cfg.transpose_comm_backend, cd.cudecompTransposeCommBackendToString(cfg.transpose_comm_backend))
 
-    es = 8
-    pinfo = [cd.cudecompGetPencilInfo(h, gd, ax) for ax in range(3)]
-    nel = max(p.size for p in pinfo)
-    wsz = cd.cudecompGetTransposeWorkspaceSize(h, gd)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    # synthetic payload: random 64-bit patterns (a transpose only relocates bits)
-    a = torch.randint(-2**62, 2**62, (nel,), dtype=torch.int64, device="cuda", generator=gen)
-    b = a if args.inplace else torch.zeros_like(a)
-    work = cd.cudecompMalloc(h, gd, wsz * es)
-    stream = torch.cuda.current_stream().cuda_stream
-    checksum0 = int(a[:pinfo[0].size].sum())
+        es = 8
+        pinfo = [cd.cudecompGetPencilInfo(h, gd, ax) for ax in range(3)]
+        nel = max(p.size for p in pinfo)
+        wsz = cd.cudecompGetTransposeWorkspaceSize(h, gd)
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(1234 + rank)
+        # synthetic payload: random 64-bit patterns (a transpose only relocates bits)
+        a = torch.randint(-2**62, 2**62, (nel,), dtype=torch.int64, device="cuda", generator=gen)
+        b = a if args.inplace else torch.zeros_like(a)
+        work = cd.cudecompMalloc(h, gd, wsz * es)
+        stream = torch.cuda.current_stream().cuda_stream
+        a0 = a[:pinfo[0].size].clone()  # every cycle must return the X pencil to `a` bit for bit
 
-    def cycle():
+        def cycle():
+            cur, nxt = a, b
+            for op in cd.OPS:
+                cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DOUBLE, stream=stream)
+                if not args.inplace:
+                    cur, nxt = nxt, cur
+
+        for _ in range(args.warmup):
+            cycle()
+        torch.cuda.synchronize()
+        # per-op split (outside the timed region)
+        op_ms = []
         cur, nxt = a, b
         for op in cd.OPS:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DOUBLE, stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            op_ms.append(e0.elapsed_time(e1))
             if not args.inplace:
                 cur, nxt = nxt, cur
 
-    for _ in range(args.warmup):
-        cycle()
-    torch.cuda.synchronize()
-    # per-op split (outside the timed region)
-    op_ms = []
-    cur, nxt = a, b
-    for op in cd.OPS:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DOUBLE, stream=stream)
-        e1.record()
+        barrier()
         torch.cuda.synchronize()
-        op_ms.append(e0.elapsed_time(e1))
-        if not args.inplace:
-            cur, nxt = nxt, cur
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            cycle()
+        ev1.record()
+        torch.cuda.synchronize()
+        barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            t = torch.tensor([wall, dev_ms], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(t[0]), float(t[1])
+        ok = bool(torch.equal(a[:pinfo[0].size], a0))
+        del a0
+        if world > 1:
+            t = torch.tensor([int(ok)], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(t[0])
+        if not ok and world > 1 and attempt == 0 and used != "nccl":
+            # A transport that measures well but returns wrong data must not be reported: fall back to RCCL on the
+            # same process grid and measure again (the JSON line says so).
+            if rank == 0:
+                sys.stderr.write("bench.py: round-trip checksum FAILED with transport %s on %dx%d; re-running with RCCL\n"
+                                 % (used, pdims[0], pdims[1]))
+            fallback = "round-trip checksum failed with transport %s" % used
+            pin_backend, pin_pdims = "nccl", list(pdims)
+            del a, b
+            cd.cudecompFree(h, gd, work)
+            with c_stdout_to_stderr():
+                cd.cudecompGridDescDestroy(h, gd)
+            continue
 
-    barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        cycle()
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
-    ok = int(a[:pinfo[0].size].sum()) == checksum0  # every cycle returns the X pencil to `a`
+        # where the time goes: per-op averages of [pack | exchange | unpack] recorded by the library (max over ranks)
+        split = None
+        if world > 1:
+            rows = []
+            for op in cd.OPS:
+                t = cd.cudecompExtGetTransposeTimings(h, gd, op)
+                rows.append([t["pack_ms"], t["exchange_ms"], t["unpack_ms"]])
+            tt = torch.tensor(rows, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            split = {op: {"pack_ms": round(float(tt[i][0]), 4), "exchange_ms": round(float(tt[i][1]), 4),
+                          "unpack_ms": round(float(tt[i][2]), 4)} for i, op in enumerate(cd.OPS)}
 
-    # where the time goes: per-op averages of [pack | exchange | unpack] recorded by the library (max over ranks)
-    split = None
-    if world > 1:
-        rows = []
-        for op in cd.OPS:
-            t = cd.cudecompExtGetTransposeTimings(h, gd, op)
-            rows.append([t["pack_ms"], t["exchange_ms"], t["unpack_ms"]])
-        tt = torch.tensor(rows, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        split = {op: {"pack_ms": round(float(tt[i][0]), 4), "exchange_ms": round(float(tt[i][1]), 4),
-                      "unpack_ms": round(float(tt[i][2]), 4)} for i, op in enumerate(cd.OPS)}
-
-    # bytes this rank pushes across the half/half cut of the node per cycle (for the bisection fraction)
-    cut = 0
-    if world > 1:
-        for op in cd.OPS:
-            p = cd.cudecompExtGetTransposePlan(h, gd, op, inplace=args.inplace)
-            if p.exchange:
-                for d in range(p.nranks):
-                    peer = p.member_global_rank[d]
-                    if (peer < world // 2) != (rank < world // 2):
-                        cut += p.send_cnt[d] * es
-        t = torch.tensor([cut], dtype=torch.int64)
-        dist.all_reduce(t)
-        cut = int(t[0])
+        # bytes this rank pushes across the half/half cut of the node per cycle (for the bisection fraction)
+        cut = 0
+        if world > 1:
+            for op in cd.OPS:
+                p = cd.cudecompExtGetTransposePlan(h, gd, op, inplace=args.inplace)
+                if p.exchange:
+                    for d in range(p.nranks):
+                        peer = p.member_global_rank[d]
+                        if (peer < world // 2) != (rank < world // 2):
+                            cut += p.send_cnt[d] * es
+            t = torch.tensor([cut], dtype=torch.int64)
+            dist.all_reduce(t)
+            cut = int(t[0])
+        break
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -281,7 +302,7 @@ def main():
                                       "in-place" if args.inplace else "out-of-place"),
                        "pdims": list(pdims), "transport": used, "autotuned": autotuned,
                        "per_op_ms": [round(x, 4) for x in op_ms], "per_op_split": split,
-                       "round_trip_checksum_ok": bool(ok)},
+                       "round_trip_checksum_ok": bool(ok), "fallback": fallback},
             "roofline": roof,
         }
         if world > 1:
