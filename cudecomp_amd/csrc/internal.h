@@ -57,6 +57,7 @@ struct cudecompHandle {
   int performance_report_warmup_samples = 3;  // first calls of a configuration that are not sampled
   std::string performance_report_write_dir;   // CSV output directory ("" = none)
   bool col_major_env_warned = false;
+  bool ipc_warned = false;
 
   cudecomp::KernelTuning tuning;
   int next_barrier_slot = 0;  // communicator slots are handed out round-robin, identically on every rank

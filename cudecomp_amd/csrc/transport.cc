@@ -2,6 +2,7 @@
 #include "transport.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 
 #include <fcntl.h>
@@ -101,9 +102,16 @@ class PeerContext {
       unsigned long long bytes;
       int pid;
     };
+    // Failures are agreed on collectively (a rank that threw on its own would leave the others waiting in the
+    // next collective): everybody tries, then everybody learns whether anybody failed.
     Wire mine{};
-    CD_CHECK_HIP(hipIpcGetMemHandle(&mine.handle, base));
-    mine.bytes = bytes;
+    std::string error;
+    hipError_t e = hipIpcGetMemHandle(&mine.handle, base);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      error = std::string("hipIpcGetMemHandle failed: ") + hipGetErrorString(e);
+    }
+    mine.bytes = error.empty() ? bytes : 0;  // 0 = "I have nothing to offer"
     mine.pid = (int)::getpid();
     std::vector<Wire> all(h_->nranks);
     h_->boot->allgather(&mine, all.data(), sizeof(Wire));
@@ -112,22 +120,31 @@ class PeerContext {
     r.bytes = bytes;
     r.from_library = from_library;
     r.peer_base.assign(h_->nranks, nullptr);
-    for (int p = 0; p < h_->nranks; ++p) {
+    for (int p = 0; p < h_->nranks && error.empty(); ++p) {
       if (p == h_->rank) {
         r.peer_base[p] = r.base;
         continue;
       }
       if (h_->hostnames[p] != h_->hostnames[h_->rank]) continue;  // no xGMI path: not mappable
+      if (all[p].bytes == 0) {
+        error = "a peer rank could not export its buffer over IPC";
+        break;
+      }
       void* mapped = nullptr;
-      hipError_t e = hipIpcOpenMemHandle(&mapped, all[p].handle, hipIpcMemLazyEnablePeerAccess);
+      e = hipIpcOpenMemHandle(&mapped, all[p].handle, hipIpcMemLazyEnablePeerAccess);
       if (e != hipSuccess) {
         (void)hipGetLastError();
-        CD_PEER_ERROR(std::string("hipIpcOpenMemHandle failed: ") + hipGetErrorString(e) +
-                      " (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)");
+        error = std::string("hipIpcOpenMemHandle failed: ") + hipGetErrorString(e) +
+                " (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)";
+        break;
       }
       r.peer_base[p] = static_cast<char*>(mapped);
     }
-    h_->boot->barrier();
+    const bool anyone_failed = h_->boot->allreduceOr(!error.empty());  // also: everybody has finished mapping
+    if (anyone_failed) {
+      closePeers(r);
+      CD_PEER_ERROR(error.empty() ? std::string("IPC mapping failed on another rank") : error);
+    }
     auto ins = regions_.emplace(r.base, std::move(r));
     return &ins.first->second;
   }
@@ -353,9 +370,14 @@ void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
     CD_CHECK_HIP(hipMalloc(&ptr, bytes));
     try {
       h->peer->registerRegion(ptr, bytes, true);
-    } catch (...) {
-      (void)hipFree(ptr);
-      throw;
+    } catch (const Error& e) {
+      // Agreed on by all ranks (registerRegion fails collectively).  The buffer is still a valid workspace for the
+      // RCCL / MPI transports; an operation that needs the one-sided transport will report the IPC problem itself.
+      if (h->rank == 0 && !h->ipc_warned) {
+        fprintf(stderr, "CUDECOMP:WARN: workspace could not be shared over IPC (%s); one-sided (NVSHMEM*/default MPI*) "
+                        "backends are unavailable with it\n", e.what());
+      }
+      h->ipc_warned = true;
     }
     return ptr;
   }
