@@ -1,0 +1,274 @@
+// native_test.h -- shared pieces of the native (C++) test programs in this directory.
+//
+// transpose_test / halo_test take the SAME command lines, test-file mode and output protocol as the reference's
+// tests/cc/transpose_test.cc and tests/cc/halo_test.cc ("command: ...", " PASSED" / " FAILED", "Passed all tests."),
+// so the reference's tests/test_runner.py and its case matrices can drive this library unchanged
+// (`--launcher_cmd "mpirun -np 4"` works: ranks are discovered from the launcher environment).  The programs are
+// written against the public C API only and check every result against the closed-form pencil contents
+// (value = gx + X*(gy + Y*gz) at interior cells, -1 elsewhere; periodic wrap for halos).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <array>
+#include <chrono>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cudecomp.h"
+
+#if defined(R32)
+using elem_t = float;
+static const cudecompDataType_t kDtype = CUDECOMP_FLOAT;
+#elif defined(C32)
+using elem_t = std::complex<float>;
+static const cudecompDataType_t kDtype = CUDECOMP_FLOAT_COMPLEX;
+#elif defined(C64)
+using elem_t = std::complex<double>;
+static const cudecompDataType_t kDtype = CUDECOMP_DOUBLE_COMPLEX;
+#else
+using elem_t = double;
+static const cudecompDataType_t kDtype = CUDECOMP_DOUBLE;
+#endif
+
+inline void make(float& e, double v) { e = (float)v; }
+inline void make(double& e, double v) { e = v; }
+inline void make(std::complex<float>& e, double v) { e = std::complex<float>((float)v, (float)-v); }
+inline void make(std::complex<double>& e, double v) { e = std::complex<double>(v, -v); }
+
+struct TestFailure : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+#define T_CHECK_HIP(x)                                                                                   \
+  do {                                                                                                   \
+    hipError_t e_ = (x);                                                                                 \
+    if (e_ != hipSuccess) throw TestFailure(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #x); \
+  } while (0)
+#define T_CHECK_CD(x)                                                                                    \
+  do {                                                                                                   \
+    cudecompResult_t r_ = (x);                                                                           \
+    if (r_ != CUDECOMP_RESULT_SUCCESS) throw TestFailure("cuDecomp error " + std::to_string((int)r_) + " at " #x); \
+  } while (0)
+
+// ---- command lines: "--name v1 [v2 v3 ...]" and single-letter flags, from argv or from one line of a test file ----
+struct Options {
+  std::map<std::string, std::vector<std::string>> values;
+  bool has(const std::string& k) const { return values.count(k) != 0; }
+  int geti(const std::string& k, int dflt, size_t idx = 0) const {
+    auto it = values.find(k);
+    return (it == values.end() || it->second.size() <= idx) ? dflt : std::atoi(it->second[idx].c_str());
+  }
+  std::array<int, 3> get3(const std::string& k, std::array<int, 3> dflt) const {
+    auto it = values.find(k);
+    if (it == values.end() || it->second.size() < 3) return dflt;
+    return {std::atoi(it->second[0].c_str()), std::atoi(it->second[1].c_str()), std::atoi(it->second[2].c_str())};
+  }
+};
+
+inline bool isOptionToken(const std::string& t) {
+  return t.size() >= 2 && t[0] == '-' && !(t[1] >= '0' && t[1] <= '9');
+}
+
+inline Options parseOptions(const std::string& line) {
+  Options o;
+  std::istringstream in(line);
+  std::string tok, cur;
+  while (in >> tok) {
+    if (isOptionToken(tok)) {
+      cur = tok.substr(tok[1] == '-' ? 2 : 1);
+      o.values[cur];
+    } else if (!cur.empty()) {
+      o.values[cur].push_back(tok);
+    }
+  }
+  return o;
+}
+
+// ---- launcher environment ---------------------------------------------------------------------------------------
+inline int envRankOr(const char* const* names, int dflt) {
+  for (int i = 0; names[i]; ++i)
+    if (const char* v = std::getenv(names[i])) return std::atoi(v);
+  return dflt;
+}
+inline int worldRank() {
+  static const char* n[] = {"RANK", "PMI_RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID", nullptr};
+  return envRankOr(n, 0);
+}
+inline int worldSize() {
+  static const char* n[] = {"WORLD_SIZE", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS", nullptr};
+  return envRankOr(n, 1);
+}
+inline int localRank() {
+  static const char* n[] = {"LOCAL_RANK", "MPI_LOCALRANKID", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID", nullptr};
+  return envRankOr(n, worldRank());
+}
+
+// Verdict of a case over all ranks without MPI: every rank drops a one-byte file into a job directory under /dev/shm,
+// rank 0 collects them (the ranks of these tests share a node).  Returns the maximum over ranks on rank 0.
+inline int reduceVerdict(int mine, int case_index) {
+  const int rank = worldRank(), n = worldSize();
+  if (n == 1) return mine;
+  const char* job = std::getenv("CUDECOMP_BOOTSTRAP_PORT");
+  if (!job) job = std::getenv("MASTER_PORT");
+  if (!job) job = std::getenv("PMI_ID");
+  const std::string dir = std::string("/dev/shm/cudecomp_native_") + (job ? job : "job");
+  ::mkdir(dir.c_str(), 0700);
+  auto name = [&](int r) { return dir + "/case" + std::to_string(case_index) + "_rank" + std::to_string(r); };
+  {
+    const std::string tmp = name(rank) + ".tmp";
+    std::ofstream(tmp) << mine;
+    ::rename(tmp.c_str(), name(rank).c_str());
+  }
+  if (rank != 0) return mine;
+  int worst = mine;
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300);
+  for (int r = 0; r < n; ++r) {
+    for (;;) {
+      std::ifstream f(name(r));
+      int v;
+      if (f && (f >> v)) {
+        worst = std::max(worst, v);
+        break;
+      }
+      if (std::chrono::steady_clock::now() > deadline) return 1;
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+    ::unlink(name(r).c_str());
+  }
+  return worst;
+}
+
+// ---- closed-form pencil contents ------------------------------------------------------------------------------------
+// interior cells hold their global linear index; `wrap`: halo cells hold the periodic neighbour's value (or -1
+// where the domain ends), padding -1.  Without `wrap` everything outside the interior is -1.
+inline void fillPencil(std::vector<elem_t>& out, const cudecompPencilInfo_t& p, const std::array<int, 3>& g, bool wrap,
+                       const std::array<bool, 3>& periods) {
+  out.resize(p.size);
+  int64_t idx = 0;
+  for (int i2 = 0; i2 < p.shape[2]; ++i2)
+    for (int i1 = 0; i1 < p.shape[1]; ++i1)
+      for (int i0 = 0; i0 < p.shape[0]; ++i0, ++idx) {
+        const int l[3] = {i0, i1, i2};
+        int64_t gc[3];
+        bool valid = true;
+        for (int k = 0; k < 3; ++k) {
+          const int ax = p.order[k], h = p.halo_extents[ax];
+          const int interior = p.hi[k] - p.lo[k] + 1;
+          int64_t c = p.lo[k] + (l[k] - h);
+          if (l[k] >= interior + 2 * h) valid = false;  // padding
+          if (l[k] < h || l[k] >= interior + h) {       // halo cell
+            if (!wrap) valid = false;
+            else if (c < 0 || c >= g[ax]) {
+              if (periods[ax]) c = ((c % g[ax]) + g[ax]) % g[ax];
+              else valid = false;
+            }
+          }
+          gc[ax] = c;
+        }
+        make(out[idx], valid ? (double)(gc[0] + g[0] * (gc[1] + (int64_t)g[1] * gc[2])) : -1.0);
+      }
+}
+
+// compare: the interior only (transposes leave halos unspecified) or the whole pencil (halo updates)
+inline int64_t countMismatches(const std::vector<elem_t>& got, const std::vector<elem_t>& ref, const cudecompPencilInfo_t& p,
+                               bool interior_only) {
+  int64_t bad = 0, idx = 0;
+  for (int i2 = 0; i2 < p.shape[2]; ++i2)
+    for (int i1 = 0; i1 < p.shape[1]; ++i1)
+      for (int i0 = 0; i0 < p.shape[0]; ++i0, ++idx) {
+        if (interior_only) {
+          const int l[3] = {i0, i1, i2};
+          bool inside = true;
+          for (int k = 0; k < 3; ++k) {
+            const int h = p.halo_extents[p.order[k]];
+            if (l[k] < h || l[k] >= (p.hi[k] - p.lo[k] + 1) + h) inside = false;
+          }
+          if (!inside) continue;
+        }
+        if (!(got[idx] == ref[idx])) ++bad;
+      }
+  return bad;
+}
+
+inline std::vector<std::string> readTestFile(const std::string& path) {
+  std::vector<std::string> lines;
+  std::ifstream f(path);
+  if (!f) throw TestFailure("cannot open test file " + path);
+  std::string line;
+  while (std::getline(f, line))
+    if (line.find_first_not_of(" \t\r") != std::string::npos) lines.push_back(line);
+  return lines;
+}
+
+// main loop shared by both programs: argv or --testfile, the reference's output protocol
+template <typename RunCase>
+int nativeMain(int argc, char** argv, RunCase run_case) {
+  const int rank = worldRank();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "No HIP devices available.\n");
+    return EXIT_FAILURE;
+  }
+  (void)hipSetDevice(localRank() % ndev);
+
+  std::string testfile;
+  for (int i = 1; i + 1 < argc; ++i)
+    if (!strcmp(argv[i], "-f") || !strcmp(argv[i], "--testfile")) testfile = argv[i + 1];
+  std::vector<std::string> cases;
+  const bool from_file = !testfile.empty();
+  if (from_file) {
+    cases = readTestFile(testfile);
+  } else {
+    std::string line;
+    for (int i = 1; i < argc; ++i) line += std::string(i > 1 ? " " : "") + argv[i];
+    cases.push_back(line);
+  }
+
+  cudecompHandle_t handle;
+  if (cudecompInit(&handle, MPI_COMM_WORLD) != CUDECOMP_RESULT_SUCCESS) return EXIT_FAILURE;
+  std::vector<std::string> failed;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  if (from_file && rank == 0) printf("Running %d tests...\n", (int)cases.size());
+  int any_local_failure = 0;
+  for (size_t i = 0; i < cases.size(); ++i) {
+    if (from_file && rank == 0) printf("command: %s %s\n", argv[0], cases[i].c_str());
+    int res = 1;
+    try {
+      res = run_case(handle, parseOptions(cases[i]), from_file);
+    } catch (const std::exception& e) {
+      fprintf(stderr, "rank %d: %s\n", rank, e.what());
+    }
+    any_local_failure |= res;
+    res = reduceVerdict(res, (int)i);
+    if (rank == 0) {
+      if (from_file) printf(res ? " FAILED\n" : " PASSED\n");
+      if (res) failed.push_back(cases[i]);
+      if (from_file && (i + 1) % 10 == 0)
+        printf("Completed %d/%d tests, running time %f s\n", (int)i + 1, (int)cases.size(), elapsed());
+      fflush(stdout);
+    }
+  }
+  (void)cudecompFinalize(handle);
+  if (rank == 0) {
+    if (from_file) printf("Completed all tests, running time %f s,\n", elapsed());
+    if (failed.empty()) {
+      printf(from_file ? "Passed all tests.\n" : "PASSED\n");
+    } else {
+      printf("Failed %d/%d tests. Failing cases:\n", (int)failed.size(), (int)cases.size());
+      for (auto& c : failed) printf("%s %s\n", argv[0], c.c_str());
+    }
+    return failed.empty() ? EXIT_SUCCESS : EXIT_FAILURE;
+  }
+  return any_local_failure ? EXIT_FAILURE : EXIT_SUCCESS;
+}

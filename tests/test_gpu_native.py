@@ -1,0 +1,108 @@
+"""Native test programs (tests/native): the reference's transpose_test / halo_test command lines, test-file mode and
+output protocol, implemented against the public C API.  The case files written here follow the structure of the
+reference's tests/test_config.yaml sweeps (grid 128 x 124 x 132 there; a smaller uneven grid here to bound GPU time):
+backends x axis-contiguous flags x gdims_dist x halos x padding x in/out of place, memory orders, autotuning, all four
+data types.  A maintainer can equally point the reference's tests/test_runner.py at these binaries."""
+import itertools
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+from tests.mp import ROOT, run_binary_ranks
+
+pytestmark = pytest.mark.gpu
+NATIVE = os.path.join(ROOT, "tests", "native")
+SHIM = os.path.join(ROOT, "tests", "shim", "libfake_rccl.so")
+
+
+def _binary(name):
+    path = os.path.join(NATIVE, "build", name)
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", NATIVE, "build/" + name], check=True, capture_output=True)
+    return path
+
+
+def _run(binary, nranks, lines, env=None):
+    with tempfile.NamedTemporaryFile("w", suffix="_cases.txt", delete=False) as f:
+        f.write("\n".join(lines) + "\n")
+        path = f.name
+    try:
+        logs = run_binary_ranks(nranks, [_binary(binary), "--testfile", path], timeout=900, extra_env=env)
+    finally:
+        os.unlink(path)
+    out = logs[0]
+    assert out.count(" PASSED") == len(lines) and " FAILED" not in out and "Passed all tests." in out, out[-3000:]
+
+
+def _transpose_lines(pdims_list, backends, full):
+    lines = []
+    acs = [(0, 0, 0), (1, 1, 1), (1, 0, 1)] if full else [(0, 0, 0), (1, 1, 1)]
+    extras = [("0 0 0", "0 0 0", "0 0 0", "0 0 0", "0 0 0"),      # gd, hex=hez, hey, pdx=pdz, pdy
+              ("1 2 3", "1 1 1", "0 0 0", "0 0 0", "1 0 2"),
+              ("0 0 0", "2 1 1", "1 2 1", "1 1 0", "0 0 0")]
+    for (pr, pc), b, ac, (gd, hxz, hy, pxz, py), oop in itertools.product(pdims_list, backends, acs, extras, ("", "-o")):
+        lines.append("--pr %d --pc %d --gx 32 --gy 30 --gz 34 --backend %d --acx %d --acy %d --acz %d --gd %s --hex %s "
+                     "--hey %s --hez %s --pdx %s --pdy %s --pdz %s %s" % (pr, pc, b, ac[0], ac[1], ac[2], gd, hxz, hy, hxz,
+                                                                        pxz, py, pxz, oop))
+    return lines
+
+
+@pytest.mark.parametrize("dtype", ["R32", "R64", "C32", "C64"])
+def test_native_transpose_single_rank(dtype):
+    lines = _transpose_lines([(1, 1)], [4], full=(dtype == "R64"))
+    if dtype == "R64":  # memory-order sweep: same order for X and Z pencils, as the reference's runner generates it
+        perms = [" ".join(map(str, p)) for p in itertools.permutations((0, 1, 2))]
+        lines += ["--pr 1 --pc 1 --gx 20 --gy 18 --gz 22 --backend 4 --mem_order %s %s %s %s" % (x, y, x, o)
+                  for x, y in itertools.product(perms, perms) for o in ("", "-o")]
+    _run("transpose_test_" + dtype, 1, lines)
+
+
+@pytest.mark.parametrize("dtype", ["R64", "C32"])
+def test_native_transpose_four_ranks(dtype):
+    backends = [1, 2, 3, 6, 7, 8] if dtype == "R64" else [1, 8]
+    lines = _transpose_lines([(2, 2), (1, 4), (4, 1)], backends, full=False)
+    lines += ["--pr 0 --pc 0 --gx 32 --gy 30 --gz 34 --backend 0 --acx 1 --acy 1 --acz 1",      # grid + backend autotuning
+              "--pr 2 --pc 2 --gx 32 --gy 30 --gz 34 --backend 0 -o",
+              "--pr 2 --pc 2 --rank-order 2 --gx 32 --gy 30 --gz 34 --backend 1 --gd 1 1 1"]
+    env = {"CUDECOMP_AUTOTUNE_TRANSPOSE_BACKENDS": "^NCCL,NCCL_PL"}  # RCCL cannot place four ranks on one GPU
+    _run("transpose_test_" + dtype, 4, lines, env)
+
+
+def test_native_transpose_four_ranks_rccl_code_path():
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim/libfake_rccl.so not built")
+    lines = _transpose_lines([(2, 2), (1, 4)], [4, 5], full=False)
+    _run("transpose_test_R64", 4, lines, {"LD_PRELOAD": SHIM})
+
+
+def _halo_lines(pdims_list, backends):
+    lines = []
+    for (pr, pc), b, ax, ac, (h, per, pad) in itertools.product(
+            pdims_list, backends, (0, 1, 2), (0, 1),
+            [((1, 1, 1), (1, 1, 1), (0, 0, 0)), ((2, 1, 2), (1, 0, 1), (1, 0, 2)), ((1, 2, 0), (0, 0, 0), (0, 1, 0))]):
+        lines.append("--pr %d --pc %d --gx 16 --gy 20 --gz 18 --backend %d --ax %d --ac %d --hex %d --hey %d --hez %d "
+                     "--hpx %d --hpy %d --hpz %d --pdx %d --pdy %d --pdz %d" % ((pr, pc, b, ax, ac) + h + per + pad))
+    return lines
+
+
+@pytest.mark.parametrize("dtype", ["R32", "R64", "C32", "C64"])
+def test_native_halo_single_rank(dtype):
+    lines = _halo_lines([(1, 1)], [3])
+    if dtype == "R64":
+        lines += ["--pr 1 --pc 1 --gx 12 --gy 14 --gz 10 --backend 3 --ax %d --mem_order %d %d %d --hex 1 --hey 2 --hez 1"
+                  % ((ax,) + p) for ax in range(3) for p in itertools.permutations((0, 1, 2))]
+    _run("halo_test_" + dtype, 1, lines)
+
+
+def test_native_halo_four_ranks():
+    lines = _halo_lines([(2, 2), (1, 4), (4, 1)], [1, 2, 4, 5])
+    lines += ["--pr 0 --pc 0 --gx 16 --gy 20 --gz 18 --backend 0 --ax 1 --hex 1 --hey 1 --hez 1"]  # autotuned
+    _run("halo_test_R64", 4, lines, {"CUDECOMP_AUTOTUNE_HALO_BACKENDS": "^NCCL"})
+
+
+def test_native_halo_four_ranks_rccl_code_path():
+    if not os.path.exists(SHIM):
+        pytest.skip("tests/shim/libfake_rccl.so not built")
+    _run("halo_test_R64", 4, _halo_lines([(2, 2), (4, 1)], [3]), {"LD_PRELOAD": SHIM})
