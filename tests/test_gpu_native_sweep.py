@@ -1,0 +1,115 @@
+"""The reference's own sweep structure (tests/test_config.yaml: transpose_test, _halo, _padding, _gdimdist, _mix, _ac,
+_rank_order and the halo_test family, with the skip rules of tests/test_runner.py:28-77) re-expressed as case files for
+the native test programs, at the reference's grid sizes (128 x 124 x 132 / 128 x 132 x 124) on 4 ranks with the process
+grids its runner derives (pr in {1, 2, 4}).  Memory-order sweeps ("x y x" over all permutations) are kept for the base
+configurations; managed-memory variants have no counterpart here.  RCCL backends run through the test-only stand-in
+(tests/shim) because four ranks share one GPU on the test box."""
+import itertools
+import os
+
+import pytest
+
+from tests.test_gpu_native import SHIM, _run
+
+pytestmark = pytest.mark.gpu
+PERMS = [" ".join(map(str, p)) for p in itertools.permutations((0, 1, 2))]
+PDIMS = [(1, 4), (2, 2), (4, 1)]
+Z = "0 0 0"
+
+
+def _tcase(pr, pc, backend, gd=Z, hx=Z, hy=Z, hz=Z, px=Z, py=Z, pz=Z, extra="", oop=False):
+    return ("--pr %d --pc %d --backend %d --gx 128 --gy 124 --gz 132 --gd %s --hex %s --hey %s --hez %s --pdx %s --pdy %s "
+            "--pdz %s %s %s" % (pr, pc, backend, gd, hx, hy, hz, px, py, pz, extra, "-o" if oop else "")).strip()
+
+
+def _mem_orders():
+    return ["--mem_order %s %s %s" % (x, y, x) for x, y in itertools.product(PERMS, PERMS)]
+
+
+@pytest.mark.parametrize("backends,shim", [([1, 2, 3, 6, 7, 8], False), ([4, 5], True)], ids=["one_sided", "rccl_path"])
+def test_sweep_transpose_base_all_memory_orders(backends, shim):
+    if shim and not os.path.exists(SHIM):
+        pytest.skip("tests/shim/libfake_rccl.so not built")
+    lines = [_tcase(pr, pc, b, extra=mo, oop=oop) for (pr, pc), b, mo, oop in
+             itertools.product(PDIMS, backends, _mem_orders(), (True, False))]
+    _run("transpose_test_R64", 4, lines, {"LD_PRELOAD": SHIM} if shim else None)
+
+
+@pytest.mark.parametrize("dtype", ["R32", "C32", "C64"])
+def test_sweep_transpose_base_other_dtypes(dtype):
+    lines = [_tcase(pr, pc, b, extra=mo, oop=oop) for (pr, pc), b, mo, oop in
+             itertools.product(PDIMS, [1, 8], _mem_orders()[::5], (True, False))]
+    _run("transpose_test_" + dtype, 4, lines)
+
+
+def _nonzero_pairs():
+    """(X=Z value, Y value) combinations of the halo / padding sweeps after the runner's skips (X and Z equal,
+    not all zero)."""
+    return [(xz, y) for xz, y in itertools.product((Z, "1 1 1"), (Z, "1 1 1")) if (xz, y) != (Z, Z)]
+
+
+def test_sweep_transpose_halo_padding_gdimdist_mix():
+    lines = []
+    acs = ["--acx 0 --acy 0 --acz 0", "--acx 1 --acy 1 --acz 1"]
+    for (pr, pc), b, ac, oop in itertools.product(PDIMS, [1, 2], acs, (True, False)):
+        for hxz, hy in _nonzero_pairs():                                   # transpose_test_halo
+            lines.append(_tcase(pr, pc, b, hx=hxz, hy=hy, hz=hxz, extra=ac, oop=oop))
+        for pxz, py in _nonzero_pairs():                                   # transpose_test_padding
+            lines.append(_tcase(pr, pc, b, px=pxz, py=py, pz=pxz, extra=ac, oop=oop))
+        for (hxz, hy), (pxz, py) in itertools.product(_nonzero_pairs(), _nonzero_pairs()):  # transpose_test_mix
+            lines.append(_tcase(pr, pc, b, hx=hxz, hy=hy, hz=hxz, px=pxz, py=py, pz=pxz, extra=ac, oop=oop))
+    for (pr, pc), mo, oop in itertools.product(PDIMS, _mem_orders()[::3], (True, False)):  # transpose_test_gdimdist
+        lines.append(_tcase(pr, pc, 1, gd="16 16 16", extra=mo, oop=oop))
+    _run("transpose_test_R32", 4, lines)
+
+
+def test_sweep_transpose_ac_and_rank_order():
+    lines = [_tcase(pr, pc, 1, extra="--acx %d --acy %d --acz %d" % ac, oop=oop) for (pr, pc), ac, oop in
+             itertools.product(PDIMS, itertools.product((0, 1), repeat=3), (True, False))]
+    lines += [_tcase(pr, pc, 1, extra="--rank-order %d" % ro) for (pr, pc), ro in itertools.product(PDIMS, (0, 1, 2))]
+    _run("transpose_test_R32", 4, lines)
+
+
+def _hcase(pr, pc, backend, ax, gd=Z, h=(1, 1, 1), per=(1, 1, 1), pad=(0, 0, 0), extra=""):
+    return ("--pr %d --pc %d --backend %d --gx 128 --gy 132 --gz 124 --gd %s --hex %d --hey %d --hez %d --hpx %d --hpy %d "
+            "--hpz %d --pdx %d --pdy %d --pdz %d --ax %d %s" % ((pr, pc, backend, gd) + tuple(h) + tuple(per) + tuple(pad) +
+                                                                (ax, extra))).strip()
+
+
+@pytest.mark.parametrize("backends,shim", [([1, 2, 4, 5], False), ([3], True)], ids=["one_sided", "rccl_path"])
+@pytest.mark.parametrize("dtype", ["R64", "C32"])
+def test_sweep_halo_base_all_memory_orders(backends, shim, dtype):
+    if shim and not os.path.exists(SHIM):
+        pytest.skip("tests/shim/libfake_rccl.so not built")
+    lines = [_hcase(pr, pc, b, ax, extra="--mem_order " + mo) for (pr, pc), b, ax, mo in
+             itertools.product(PDIMS, backends, (0, 1, 2), PERMS)]
+    _run("halo_test_" + dtype, 4, lines, {"LD_PRELOAD": SHIM} if shim else None)
+
+
+def _halo_period_combos():
+    """halo_test_halomix after the runner's skips: no periodic flag on a zero halo, not all halos zero."""
+    out = []
+    for h in itertools.product((0, 1), repeat=3):
+        for per in itertools.product((0, 1), repeat=3):
+            if any(hh == 0 and pp == 1 for hh, pp in zip(h, per)) or h == (0, 0, 0):
+                continue
+            out.append((h, per))
+    return out
+
+
+def test_sweep_halo_mix_padding_gdimdist_ac_rank_order():
+    lines = []
+    pads = [p for p in itertools.product((0, 1), repeat=3) if p != (0, 0, 0)]
+    for (pr, pc), ax in itertools.product(PDIMS, (0, 1, 2)):
+        for h, per in _halo_period_combos():                                # halo_test_halomix
+            lines.append(_hcase(pr, pc, 1, ax, h=h, per=per))
+        for pad in pads:                                                    # halo_test_padding
+            lines.append(_hcase(pr, pc, 1, ax, pad=pad))
+        for (h, per), pad in itertools.product(_halo_period_combos()[::3], pads[::2]):  # halo_test_mix (thinned)
+            lines.append(_hcase(pr, pc, 1, ax, h=h, per=per, pad=pad))
+        lines.append(_hcase(pr, pc, 1, ax, gd="16 16 16"))                   # halo_test_gdimdist
+        for ac in (0, 1):                                                   # halo_test_ac
+            lines.append(_hcase(pr, pc, 1, ax, extra="--ac %d" % ac))
+        for ro in (0, 1, 2):                                                # halo_test_rank_order
+            lines.append(_hcase(pr, pc, 1, ax, extra="--rank-order %d" % ro))
+    _run("halo_test_R32", 4, lines)
