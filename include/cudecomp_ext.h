@@ -80,8 +80,8 @@ cudecompResult_t cudecompExtPlanHalo(const cudecompExtGridSpec_t* grid, int32_t 
                                      const int32_t halo_extents[], const bool halo_periods[], int32_t dim,
                                      const int32_t padding[], int32_t force_packed, cudecompExtHaloPlan_t* plan);
 
-/* Averages over the last (up to 32) calls of one transpose op, recorded when CUDECOMP_ENABLE_PERFORMANCE_REPORT=1
- * was set at cudecompInit (0 calls otherwise).  Synchronises the device.  exchange_ms is the all-to-all
+/* Averages over the retained samples (CUDECOMP_PERFORMANCE_REPORT_SAMPLES, all configurations) of one transpose op,
+ * recorded when CUDECOMP_ENABLE_PERFORMANCE_REPORT=1 was set at cudecompInit (0 calls otherwise).  Synchronises the device.  exchange_ms is the all-to-all
  * (including host-side ordering for the host-ordered transports); per-peer pipelined backends report the
  * whole operation as exchange. */
 typedef struct {
