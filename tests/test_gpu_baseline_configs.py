@@ -22,7 +22,8 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("name,nranks,args", CONFIGS, ids=[c[0] for c in CONFIGS])
-@pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_MPI_P2P, cd.TRANSPOSE_COMM_NVSHMEM_SM], ids=["peer_copy", "peer_put"])
+@pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_MPI_P2P, cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_NVSHMEM_SM],
+                         ids=["peer_copy", "peer_pipelined", "peer_put"])
 def test_full_size_cycle_properties(name, nranks, args, backend):
     res = run_ranks(nranks, "tests.gpu_bodies", "cycle_properties", dict(args, transpose_backend=backend), timeout=600)
     assert all(r["round_trip_exact"] for r in res)
