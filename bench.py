@@ -98,6 +98,16 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if not os.path.exists(os.path.join(ROOT, "cudecomp_amd", "lib", "libcudecomp.so")):
+        # binaries are git-ignored; build once (rank 0 of a multi-GPU launch, the others wait for the file)
+        import subprocess
+        if int(os.environ.get("RANK", "0")) == 0:
+            subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "cudecomp_amd")], stdout=sys.stderr)
+        else:
+            t_wait = time.time()
+            while not os.path.exists(os.path.join(ROOT, "cudecomp_amd", "lib", "libcudecomp.so")) and time.time() - t_wait < 600:
+                time.sleep(1.0)
+            time.sleep(2.0)
     import cudecomp_amd as cd
 
     rank = int(os.environ.get("RANK", "0"))
