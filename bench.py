@@ -95,6 +95,8 @@ def cpu_baseline(sample, layout):
 
 def main():
     args = parse()
+    # dmabuf IPC (the only mode the pool's hosts support) must be selected before the HIP runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
