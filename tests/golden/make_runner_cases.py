@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Regenerate tests/golden/reference_runner_cases_ngpu4.txt.gz: the case lists the reference's own
-tests/test_runner.py derives from its tests/test_config.yaml for 4 GPUs (the `*_cc` configurations), obtained by
+"""Regenerate tests/golden/reference_runner_cases_ngpu{4,8}.txt.gz: the case lists the reference's own
+tests/test_runner.py derives from its tests/test_config.yaml for 4 and 8 GPUs (the `*_cc` configurations), obtained by
 running that runner with a stand-in launcher that keeps the generated `<config>_cases.txt` and launches nothing.
 Lines with the managed-memory flag (-m) are dropped: this library has no managed-memory special case, so they would
 repeat their neighbours.  Needs /root/reference (development container only); the fixture is what travels.
@@ -30,16 +30,21 @@ def main():
     with open(launcher, "w") as f:
         f.write('#!/bin/bash\nfor a in "$@"; do :; done\ncp "$a" "%s/kept_$(basename "$a")"\necho "Passed all tests."\n' % work)
     os.chmod(launcher, os.stat(launcher).st_mode | stat.S_IEXEC)
+    for ngpu in (4, 8):
+        generate(ref, work, launcher, here, ngpu)
+
+
+def generate(ref, work, launcher, here, ngpu):
     out = []
     for cfg in CONFIGS:
         subprocess.run([sys.executable, os.path.join(ref, "tests", "test_runner.py"), "--launcher_cmd", launcher, "--ngpu",
-                        "4", cfg], cwd=work, check=True, capture_output=True)
+                        str(ngpu), cfg], cwd=work, check=True, capture_output=True)
         with open(os.path.join(work, "kept_%s_cases.txt" % cfg)) as f:
             lines = [" ".join(l.split()) for l in f if l.strip()]
         kept = [l for l in lines if "-m" not in l.split()]
         out.append("# config: %s (%d of %d lines, managed-memory variants dropped)" % (cfg, len(kept), len(lines)))
         out.extend(kept)
-    path = os.path.join(here, "reference_runner_cases_ngpu4.txt.gz")
+    path = os.path.join(here, "reference_runner_cases_ngpu%d.txt.gz" % ngpu)
     with gzip.GzipFile(path, "wb", mtime=0) as f:
         f.write(("\n".join(out) + "\n").encode())
     print(path, os.path.getsize(path), "bytes,", sum(1 for l in out if not l.startswith("#")), "cases")
