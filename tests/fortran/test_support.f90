@@ -58,7 +58,159 @@ module test_support
 
   integer :: nfail = 0
 
+  ! one command line, split at blanks ("--name v1 v2 ..." options and single-letter flags, the reference's test CLI)
+  integer, parameter :: MAXTOK = 96
+  type :: cmdline
+    integer :: n = 0
+    character(len=48) :: tok(MAXTOK)
+  end type cmdline
+
 contains
+
+  subroutine tokenize(line, c)
+    character(len=*), intent(in) :: line
+    type(cmdline), intent(out) :: c
+    integer :: i, start
+    logical :: in_tok
+    c%n = 0
+    in_tok = .false.
+    start = 1
+    do i = 1, len_trim(line) + 1
+      if (i <= len_trim(line) .and. line(i:min(i, len(line))) /= ' ') then
+        if (.not. in_tok) then
+          in_tok = .true.
+          start = i
+        end if
+      else if (in_tok) then
+        in_tok = .false.
+        if (c%n < MAXTOK) then
+          c%n = c%n + 1
+          c%tok(c%n) = line(start:i - 1)
+        end if
+      end if
+    end do
+  end subroutine tokenize
+
+  integer function find_opt(c, name)
+    type(cmdline), intent(in) :: c
+    character(len=*), intent(in) :: name
+    integer :: i
+    find_opt = 0
+    do i = 1, c%n
+      if (trim(c%tok(i)) == name) find_opt = i
+    end do
+  end function find_opt
+
+  ! the integers that follow option `name` (as many as vals holds); vals keeps its content when the option is absent
+  subroutine opt_ints(c, name, vals)
+    type(cmdline), intent(in) :: c
+    character(len=*), intent(in) :: name
+    integer, intent(inout) :: vals(:)
+    integer :: i, k, stat, v
+    i = find_opt(c, name)
+    if (i == 0) return
+    do k = 1, size(vals)
+      if (i + k > c%n) exit
+      read (c%tok(i + k), *, iostat=stat) v
+      if (stat /= 0) exit
+      vals(k) = v
+    end do
+  end subroutine opt_ints
+
+  integer function opt_int(c, name, default)
+    type(cmdline), intent(in) :: c
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: default
+    integer :: v(1)
+    v(1) = default
+    call opt_ints(c, name, v)
+    opt_int = v(1)
+  end function opt_int
+
+  ! data type of this executable from its name (transpose_test_R32, ..._R64, ..._C32, ..._C64; default R64):
+  ! 1 real32, 2 real64, 3 complex32, 4 complex64
+  integer function dtype_from_program_name()
+    character(len=512) :: name
+    integer :: n
+    call get_command_argument(0, name)
+    n = len_trim(name)
+    dtype_from_program_name = 2
+    if (n >= 4) then
+      select case (name(n - 3:n))
+      case ("_R32"); dtype_from_program_name = 1
+      case ("_R64"); dtype_from_program_name = 2
+      case ("_C32"); dtype_from_program_name = 3
+      case ("_C64"); dtype_from_program_name = 4
+      end select
+    end if
+  end function dtype_from_program_name
+
+  ! Verdict of a case over all ranks without MPI: every rank drops a file into a job directory under /dev/shm, rank 0
+  ! collects them (the ranks of these tests share a node).  Returns the maximum over ranks on rank 0.
+  integer function reduce_verdict(mine, case_index)
+    integer, intent(in) :: mine, case_index
+    integer :: rank, nranks, r, v, u, stat, worst, c0, c1, rate
+    character(len=64) :: job
+    character(len=256) :: dir, fname
+    logical :: ex
+    integer :: jl, js
+    rank = env_int("RANK", env_int("PMI_RANK", env_int("OMPI_COMM_WORLD_RANK", 0)))
+    nranks = env_int("WORLD_SIZE", env_int("PMI_SIZE", env_int("OMPI_COMM_WORLD_SIZE", 1)))
+    reduce_verdict = mine
+    if (nranks == 1) return
+    call get_environment_variable("CUDECOMP_BOOTSTRAP_PORT", job, jl, js)
+    if (js /= 0 .or. jl == 0) call get_environment_variable("MASTER_PORT", job, jl, js)
+    if (js /= 0 .or. jl == 0) then
+      job = "job"
+      jl = 3
+    end if
+    dir = "/dev/shm/cudecomp_fortran_"//job(1:jl)
+    call execute_command_line("mkdir -p "//trim(dir))
+    write (fname, '(a,a,i0,a,i0)') trim(dir), "/case", case_index, "_rank", rank
+    open (newunit=u, file=trim(fname)//".tmp", status="replace", action="write")
+    write (u, '(i0)') mine
+    close (u)
+    call rename_file(trim(fname)//".tmp", trim(fname))
+    if (rank /= 0) return
+    worst = mine
+    call system_clock(c0, rate)
+    do r = 0, nranks - 1
+      write (fname, '(a,a,i0,a,i0)') trim(dir), "/case", case_index, "_rank", r
+      do
+        inquire (file=trim(fname), exist=ex)
+        if (ex) then
+          open (newunit=u, file=trim(fname), status="old", action="read", iostat=stat)
+          if (stat == 0) then
+            read (u, *, iostat=stat) v
+            close (u, status="delete")
+            if (stat == 0) then
+              worst = max(worst, v)
+              exit
+            end if
+          end if
+        end if
+        call system_clock(c1)
+        if (real(c1 - c0)/real(rate) > 300.0) then
+          worst = 1
+          exit
+        end if
+      end do
+    end do
+    reduce_verdict = worst
+  end function reduce_verdict
+
+  subroutine rename_file(from, to)
+    character(len=*), intent(in) :: from, to
+    interface
+      function c_rename(a, b) bind(C, name="rename") result(res)
+        import
+        character(kind=c_char), intent(in) :: a(*), b(*)
+        integer(c_int) :: res
+      end function c_rename
+    end interface
+    integer(c_int) :: res
+    res = c_rename(trim(from)//c_null_char, trim(to)//c_null_char)
+  end subroutine rename_file
 
   integer function env_int(name, default)
     character(len=*), intent(in) :: name

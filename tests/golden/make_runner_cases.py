@@ -31,12 +31,14 @@ def main():
         f.write('#!/bin/bash\nfor a in "$@"; do :; done\ncp "$a" "%s/kept_$(basename "$a")"\necho "Passed all tests."\n' % work)
     os.chmod(launcher, os.stat(launcher).st_mode | stat.S_IEXEC)
     for ngpu in (4, 8):
-        generate(ref, work, launcher, here, ngpu)
+        generate(ref, work, launcher, here, ngpu, CONFIGS, "reference_runner_cases_ngpu%d.txt.gz" % ngpu)
+    # the Fortran flavour of the same sweeps (one-based --ax / --mem_order), for the twins in tests/fortran
+    generate(ref, work, launcher, here, 4, [c[:-3] + "_fortran" for c in CONFIGS], "reference_runner_cases_fortran_ngpu4.txt.gz")
 
 
-def generate(ref, work, launcher, here, ngpu):
+def generate(ref, work, launcher, here, ngpu, configs, name):
     out = []
-    for cfg in CONFIGS:
+    for cfg in configs:
         subprocess.run([sys.executable, os.path.join(ref, "tests", "test_runner.py"), "--launcher_cmd", launcher, "--ngpu",
                         str(ngpu), cfg], cwd=work, check=True, capture_output=True)
         with open(os.path.join(work, "kept_%s_cases.txt" % cfg)) as f:
@@ -44,7 +46,7 @@ def generate(ref, work, launcher, here, ngpu):
         kept = [l for l in lines if "-m" not in l.split()]
         out.append("# config: %s (%d of %d lines, managed-memory variants dropped)" % (cfg, len(kept), len(lines)))
         out.extend(kept)
-    path = os.path.join(here, "reference_runner_cases_ngpu%d.txt.gz" % ngpu)
+    path = os.path.join(here, name)
     with gzip.GzipFile(path, "wb", mtime=0) as f:
         f.write(("\n".join(out) + "\n").encode())
     print(path, os.path.getsize(path), "bytes,", sum(1 for l in out if not l.startswith("#")), "cases")

@@ -90,54 +90,73 @@ def test_fortran_workspace_sizes_match_oracle(nranks):
 
 
 # ------------------------------------------------------------------------------------------------------------
-# GPU: data path through the Fortran entry points
+# GPU: data path through the Fortran entry points.  The twins take the reference's Fortran test command lines
+# (tests/fortran/*.f90 there): one-based --ax and --mem_order, data type from the executable name.
 # backend numbers: transposes 1 MPI_P2P (xGMI peer transport in the non-MPI flavour), 4 NCCL, 6 NVSHMEM;
 # halos 1 MPI, 3 NCCL, 4 NVSHMEM
-TRANSPOSE_CASES = [
-    # nranks, gdims, pdims, backend, axis_contiguous, halo, inplace, dtype
-    (1, (16, 12, 10), (1, 1), 4, (0, 0, 0), (0, 0, 0), 0, 2),
-    (1, (16, 12, 10), (1, 1), 4, (1, 1, 1), (0, 0, 0), 0, 2),
-    (1, (33, 17, 21), (1, 1), 4, (1, 1, 1), (1, 2, 1), 0, 1),
-    (1, (33, 17, 21), (1, 1), 1, (0, 1, 0), (0, 0, 0), 1, 3),
-    (1, (20, 24, 28), (1, 1), 4, (1, 1, 1), (0, 0, 0), 1, 4),
-    (2, (16, 12, 10), (2, 1), 1, (0, 0, 0), (0, 0, 0), 0, 2),
-    (2, (31, 18, 23), (1, 2), 2, (1, 1, 1), (1, 1, 1), 0, 1),
-    (4, (32, 24, 20), (2, 2), 1, (1, 1, 1), (0, 0, 0), 0, 2),
-    (4, (19, 23, 17), (2, 2), 6, (0, 0, 0), (2, 1, 1), 1, 4),
-    (4, (19, 23, 17), (4, 1), 8, (1, 0, 1), (0, 0, 0), 0, 3),
-]
+def _fbin(name, dtype):
+    _binary(name)
+    path = os.path.join(BUILD, "fortran", "%s_%s" % (name, dtype))
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "fortran"), "tests"], check=True, capture_output=True)
+    return path
+
+
+def _run_fortran(name, dtype, nranks, lines, env=None):
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix="_cases.txt", delete=False) as f:
+        f.write("\n".join(lines) + "\n")
+        path = f.name
+    try:
+        logs = run_binary_ranks(nranks, [_fbin(name, dtype), "--testfile", path], timeout=900, extra_env=env)
+    finally:
+        os.unlink(path)
+    out = logs[0]
+    assert out.count(" PASSED") == len(lines) and " FAILED" not in out and "Passed all tests." in out, out[-3000:]
+
+
+TRANSPOSE_LINES = {
+    1: ["--pr 1 --pc 1 --gx 16 --gy 12 --gz 10 --backend 4",
+        "--pr 1 --pc 1 --gx 16 --gy 12 --gz 10 --backend 4 --acx 1 --acy 1 --acz 1 -o",
+        "--pr 1 --pc 1 --gx 33 --gy 17 --gz 21 --backend 4 --acx 1 --acy 1 --acz 1 --hex 1 2 1 --hey 1 2 1 --hez 1 2 1",
+        "--pr 1 --pc 1 --gx 33 --gy 17 --gz 21 --backend 1 --acy 1 --pdx 1 0 1 --pdz 1 0 1",
+        "--pr 1 --pc 1 --gx 20 --gy 24 --gz 28 --backend 4 --mem_order 2 3 1 1 3 2 3 1 2 -o"],
+    2: ["--pr 2 --pc 1 --gx 16 --gy 12 --gz 10 --backend 1 -o",
+        "--pr 1 --pc 2 --gx 31 --gy 18 --gz 23 --backend 2 --acx 1 --acy 1 --acz 1 --hex 1 1 1 --hey 1 1 1 --hez 1 1 1 -o"],
+    4: ["--pr 2 --pc 2 --gx 32 --gy 24 --gz 20 --backend 1 --acx 1 --acy 1 --acz 1 -o",
+        "--pr 2 --pc 2 --gx 19 --gy 23 --gz 17 --backend 6 --hex 2 1 1 --hey 2 1 1 --hez 2 1 1 --gd 1 2 1",
+        "--pr 4 --pc 1 --gx 19 --gy 23 --gz 17 --backend 8 --acx 1 --acz 1 --rank-order 2 -o",
+        "--pr 0 --pc 0 --gx 32 --gy 24 --gz 20 --backend 0 --acx 1 --acy 1 --acz 1"],
+}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", TRANSPOSE_CASES, ids=lambda c: "r%d-%s-p%dx%d-b%d-dt%d" % (
-    c[0], "x".join(map(str, c[1])), c[2][0], c[2][1], c[3], c[7]))
-def test_fortran_transpose_cycle(case):
-    nranks, gd, pd, backend, ac, halo, inplace, dtype = case
-    argv = [_binary("transpose_test"), *gd, *pd, backend, *ac, *halo, inplace, dtype]
-    rec = _records(run_binary_ranks(nranks, argv))
-    assert sorted(r[0] for r in rec["PASS"]) == list(range(nranks))
+@pytest.mark.parametrize("dtype", ["R32", "R64", "C32", "C64"])
+@pytest.mark.parametrize("nranks", [1, 2, 4])
+def test_fortran_transpose_cycle(nranks, dtype):
+    env = {"CUDECOMP_AUTOTUNE_TRANSPOSE_BACKENDS": "^NCCL,NCCL_PL"} if nranks > 1 else None
+    _run_fortran("transpose_test", dtype, nranks, TRANSPOSE_LINES[nranks], env)
 
 
-HALO_CASES = [
-    # nranks, gdims, pdims, backend, axis (one-based), halo, periods, padding, axis_contiguous
-    (1, (12, 10, 14), (1, 1), 3, 1, (1, 1, 1), (1, 1, 1), (0, 0, 0), 0),
-    (1, (12, 10, 14), (1, 1), 3, 2, (2, 1, 2), (1, 0, 1), (1, 0, 2), 0),
-    (1, (12, 10, 14), (1, 1), 1, 3, (1, 2, 1), (0, 0, 0), (0, 0, 0), 1),
-    (2, (16, 12, 10), (2, 1), 1, 1, (1, 1, 1), (1, 1, 1), (0, 0, 0), 0),
-    (4, (16, 12, 14), (2, 2), 1, 1, (2, 1, 1), (1, 0, 1), (0, 1, 0), 0),
-    (4, (16, 12, 14), (2, 2), 4, 2, (1, 1, 2), (1, 1, 0), (0, 0, 0), 1),
-    (4, (16, 12, 14), (2, 2), 2, 3, (1, 1, 1), (0, 1, 1), (2, 0, 1), 0),
-]
+HALO_LINES = {
+    1: ["--pr 1 --pc 1 --gx 12 --gy 10 --gz 14 --backend 3 --ax 1",
+        "--pr 1 --pc 1 --gx 12 --gy 10 --gz 14 --backend 3 --ax 2 --hex 2 --hey 1 --hez 2 --hpy 0 --pdx 1 --pdz 2",
+        "--pr 1 --pc 1 --gx 12 --gy 10 --gz 14 --backend 1 --ax 3 --hey 2 --hpx 0 --hpy 0 --hpz 0 --ac 1",
+        "--pr 1 --pc 1 --gx 12 --gy 10 --gz 14 --backend 3 --ax 2 --mem_order 3 1 2"],
+    2: ["--pr 2 --pc 1 --gx 16 --gy 12 --gz 10 --backend 1 --ax 1"],
+    4: ["--pr 2 --pc 2 --gx 16 --gy 12 --gz 14 --backend 1 --ax 1 --hex 2 --hpy 0 --pdy 1",
+        "--pr 2 --pc 2 --gx 16 --gy 12 --gz 14 --backend 4 --ax 2 --hez 2 --hpz 0 --ac 1",
+        "--pr 2 --pc 2 --gx 16 --gy 12 --gz 14 --backend 2 --ax 3 --hpx 0 --pdx 2 --pdz 1 --mem_order 2 1 3",
+        "--pr 0 --pc 0 --gx 16 --gy 12 --gz 14 --backend 0 --ax 2"],
+}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "r%d-p%dx%d-b%d-axis%d" % (
-    c[0], c[2][0], c[2][1], c[3], c[4]))
-def test_fortran_halo_update(case):
-    nranks, gd, pd, backend, axis, halo, periods, pad, ac = case
-    argv = [_binary("halo_test"), *gd, *pd, backend, axis, *halo, *periods, *pad, ac]
-    rec = _records(run_binary_ranks(nranks, argv))
-    assert sorted(r[0] for r in rec["PASS"]) == list(range(nranks))
+@pytest.mark.parametrize("dtype", ["R32", "R64", "C32", "C64"])
+@pytest.mark.parametrize("nranks", [1, 2, 4])
+def test_fortran_halo_update(nranks, dtype):
+    env = {"CUDECOMP_AUTOTUNE_HALO_BACKENDS": "^NCCL"} if nranks > 1 else None
+    _run_fortran("halo_test", dtype, nranks, HALO_LINES[nranks], env)
 
 
 @pytest.mark.gpu
