@@ -335,3 +335,23 @@ def repeated_cycle(rank, nranks, args):
     cd.cudecompFree(h, gd, work)
     cd.cudecompGridDescDestroy(h, gd)
     return {"failures": failures, "counters": counters}
+
+
+def malloc_timing(rank, nranks, args):
+    """Time cudecompMalloc + cudecompFree (collective: allocation, IPC export / import on every rank) per size."""
+    import time
+    h, gd, g = _setup(rank, nranks, args)
+    out = {}
+    for nbytes in args["sizes"]:
+        ptrs = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.get("reps", 5)):
+            ptrs.append(cd.cudecompMalloc(h, gd, nbytes))
+        t1 = time.perf_counter()
+        for p in ptrs:
+            cd.cudecompFree(h, gd, p)
+        t2 = time.perf_counter()
+        out[str(nbytes)] = [round((t1 - t0) / len(ptrs) * 1e3, 3), round((t2 - t1) / len(ptrs) * 1e3, 3)]
+    cd.cudecompGridDescDestroy(h, gd)
+    return out
