@@ -158,7 +158,8 @@ contains
     nranks = env_int("WORLD_SIZE", env_int("PMI_SIZE", env_int("OMPI_COMM_WORLD_SIZE", 1)))
     reduce_verdict = mine
     if (nranks == 1) return
-    call get_environment_variable("CUDECOMP_BOOTSTRAP_PORT", job, jl, js)
+    call get_environment_variable("CUDECOMP_TEST_JOB", job, jl, js)
+    if (js /= 0 .or. jl == 0) call get_environment_variable("CUDECOMP_BOOTSTRAP_PORT", job, jl, js)
     if (js /= 0 .or. jl == 0) call get_environment_variable("MASTER_PORT", job, jl, js)
     if (js /= 0 .or. jl == 0) then
       job = "job"

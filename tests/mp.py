@@ -17,12 +17,25 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_port_counter = [0]
+
+
 def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A TCP port that is free now and is unlikely to be taken before the ranks bind it: picked BELOW the kernel's
+    ephemeral range (so no other process is handed it for an outgoing connection in the meantime), walking a
+    per-process sequence."""
+    for _ in range(2000):
+        _port_counter[0] += 1
+        port = 10000 + (os.getpid() * 131 + _port_counter[0] * 17) % 20000
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", port))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return port
+    raise RuntimeError("no free TCP port found")
 
 
 def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_rank_env=None):
@@ -81,13 +94,15 @@ if __name__ == "__main__":
 def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
     """Launch a native executable (C / Fortran test twin) on N ranks with the same launcher environment;
     returns the list of per-rank stdout+stderr texts, raising on any non-zero exit."""
+    import uuid
     port_a, port_b = free_port(), free_port()
+    job = uuid.uuid4().hex[:16]  # scratch-file namespace of this launch (tests/native, tests/fortran verdict files)
     procs = []
     for r in range(nranks):
         env = dict(os.environ)
         env.update({"RANK": str(r), "WORLD_SIZE": str(nranks), "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port_a), "CUDECOMP_BOOTSTRAP_PORT": str(port_b),
-                    "CUDECOMP_BOOTSTRAP_TIMEOUT": "60", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                    "CUDECOMP_BOOTSTRAP_TIMEOUT": "60", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "CUDECOMP_TEST_JOB": job})
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([str(a) for a in argv], env=env, cwd=ROOT, stdout=subprocess.PIPE,

@@ -33,7 +33,13 @@ def _run(binary, nranks, lines, env=None):
     finally:
         os.unlink(path)
     out = logs[0]
-    assert out.count(" PASSED") == len(lines) and " FAILED" not in out and "Passed all tests." in out, out[-3000:]
+    ok = out.count(" PASSED") == len(lines) and " FAILED" not in out and "Passed all tests." in out
+    if not ok:  # keep every rank's output where gpurun merges it back
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "native_failure_%s_%d.log" % (binary, os.getpid())), "w") as f:
+            for r, text in enumerate(logs):
+                f.write("===== rank %d =====\n%s\n" % (r, text[-20000:]))
+    assert ok, out[-3000:]
 
 
 def _transpose_lines(pdims_list, backends, full):
