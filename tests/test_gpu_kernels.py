@@ -91,3 +91,31 @@ def test_large_move_exceeding_one_tile_row():
              expect_cls=1)
     run_move(4, (1024, 300, 4), (1, 1100, 1100 * 300), (1, 1024, 1024 * 300), 1100 * 300 * 4, 1024 * 300 * 4, seed=6,
              expect_cls=0)
+
+
+def test_random_moves_property_sweep():
+    """Randomly drawn 3-D block moves (extents 1..150, any source / destination permutation, halo-style row and plane
+    padding, arbitrary element offsets and so every alignment) through all kernel flavours against numpy: a sweep over
+    the space the shape-class tests above only sample."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=500, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(es=st.sampled_from([4, 8, 16]), ext=st.tuples(st.integers(1, 150), st.integers(1, 70), st.integers(1, 12)),
+           sperm=st.permutations((0, 1, 2)), dperm=st.permutations((0, 1, 2)),
+           spad=st.tuples(st.integers(0, 5), st.integers(0, 3)), dpad=st.tuples(st.integers(0, 5), st.integers(0, 3)),
+           soff=st.integers(0, 9), doff=st.integers(0, 9), seed=st.integers(0, 1 << 20))
+    def check(es, ext, sperm, dperm, spad, dpad, soff, doff, seed):
+        def strides(perm, pad):
+            # memory position i holds logical dim perm[i]; rows / planes padded like halo-carrying pencils
+            shape = [ext[p] for p in perm]
+            s_mem = [1, shape[0] + pad[0], (shape[0] + pad[0]) * (shape[1] + pad[1])]
+            out = [0, 0, 0]
+            for i, p in enumerate(perm):
+                out[p] = s_mem[i]
+            return out, s_mem[2] * shape[2]
+        ss, slen = strides(sperm, spad)
+        ds, dlen = strides(dperm, dpad)
+        run_move(es, ext, ss, ds, soff + slen + 16, doff + dlen + 16, soff, doff, seed=seed)
+
+    check()
