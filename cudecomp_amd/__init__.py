@@ -115,7 +115,8 @@ API_SYMBOLS = [
 ]
 EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecompExtMove3D",
                "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
-               "cudecompExtPlanTranspose", "cudecompExtPlanHalo"]
+               "cudecompExtPlanTranspose", "cudecompExtPlanHalo", "cudecompExtPencilInfo", "cudecompExtShiftedRank",
+               "cudecompExtWorkspaceSizes"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -183,6 +184,10 @@ def lib():
         L.cudecompExtGetCounters.argtypes = [vp, vp, C.POINTER(ExtCounters)]
         L.cudecompExtPlanTranspose.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, pi32, pi32, C.c_bool, i32,
                                                i32, i32, C.POINTER(ExtTransposePlan)]
+        L.cudecompExtPencilInfo.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, C.POINTER(PencilInfo)]
+        L.cudecompExtShiftedRank.argtypes = [C.POINTER(ExtGridSpec), i32, i32, i32, i32, C.c_bool, pi32]
+        L.cudecompExtWorkspaceSizes.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, C.POINTER(C.c_int64),
+                                                C.POINTER(C.c_int64)]
         L.cudecompExtPlanHalo.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, C.POINTER(C.c_bool), i32, pi32, i32,
                                           C.POINTER(ExtHaloPlan)]
         L.cudecompExtMove3D.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32, pi32, vp]
@@ -363,6 +368,27 @@ def cudecompExtPlanHalo(grid, rank, axis, halo_extents, halo_periods, dim, paddi
     _check(lib().cudecompExtPlanHalo(C.byref(grid), rank, axis, _i3(halo_extents), _b3(halo_periods), dim, _i3(padding),
                                      int(force_packed), C.byref(p)), "cudecompExtPlanHalo")
     return p
+
+
+def cudecompExtPencilInfo(grid, rank, axis, halo_extents=None, padding=None):
+    p = PencilInfo()
+    _check(lib().cudecompExtPencilInfo(C.byref(grid), rank, axis, _i3(halo_extents), _i3(padding), C.byref(p)),
+           "cudecompExtPencilInfo")
+    return p
+
+
+def cudecompExtShiftedRank(grid, rank, axis, dim, displacement, periodic):
+    out = C.c_int32(0)
+    _check(lib().cudecompExtShiftedRank(C.byref(grid), rank, axis, dim, displacement, bool(periodic), C.byref(out)),
+           "cudecompExtShiftedRank")
+    return out.value
+
+
+def cudecompExtWorkspaceSizes(grid, rank, axis, halo_extents):
+    t, h = C.c_int64(0), C.c_int64(0)
+    _check(lib().cudecompExtWorkspaceSizes(C.byref(grid), rank, axis, _i3(halo_extents), C.byref(t), C.byref(h)),
+           "cudecompExtWorkspaceSizes")
+    return t.value, h.value
 
 
 def cudecompExtGetCounters(handle, gd):

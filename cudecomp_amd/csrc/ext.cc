@@ -219,6 +219,67 @@ cudecompResult_t cudecompExtPlanHalo(const cudecompExtGridSpec_t* grid, int32_t 
   return CUDECOMP_RESULT_SUCCESS;
 }
 
+cudecompResult_t cudecompExtPencilInfo(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis, const int32_t halo[],
+                                       const int32_t pad[], cudecompPencilInfo_t* out) {
+  try {
+    const GridShape g = shapeFromSpec(grid);
+    if (!out) CD_INVALID_USAGE("pencil_info argument cannot be null");
+    if (axis < 0 || axis > 2) CD_INVALID_USAGE("axis argument out of range");
+    if (rank < 0 || rank >= g.pdims[0] * g.pdims[1]) CD_INVALID_USAGE("rank out of range");
+    const Pencil p = makePencil(g, gridIndexOfRank(g, rank), axis, halo, pad);
+    std::memset(out, 0, sizeof(*out));
+    for (int i = 0; i < 3; ++i) {
+      out->shape[i] = p.shape[i];
+      out->lo[i] = p.lo[i];
+      out->hi[i] = p.hi[i];
+      out->order[i] = p.order[i];
+      out->halo_extents[i] = p.halo[i];
+      out->padding[i] = p.pad[i];
+    }
+    out->size = p.size;
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtShiftedRank(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis, int32_t dim,
+                                        int32_t displacement, bool periodic, int32_t* shifted_rank) {
+  try {
+    const GridShape g = shapeFromSpec(grid);
+    if (!shifted_rank) CD_INVALID_USAGE("shifted_rank argument cannot be null");
+    if (axis < 0 || axis > 2 || dim < 0 || dim > 2) CD_INVALID_USAGE("axis/dim out of range");
+    if (rank < 0 || rank >= g.pdims[0] * g.pdims[1]) CD_INVALID_USAGE("rank out of range");
+    *shifted_rank = shiftedRank(g, rank, axis, dim, displacement, periodic);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtWorkspaceSizes(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis,
+                                           const int32_t halo[], int64_t* transpose_ws, int64_t* halo_ws) {
+  try {
+    const GridShape g = shapeFromSpec(grid);
+    if (axis < 0 || axis > 2) CD_INVALID_USAGE("axis argument out of range");
+    if (rank < 0 || rank >= g.pdims[0] * g.pdims[1]) CD_INVALID_USAGE("rank out of range");
+    if (transpose_ws) *transpose_ws = transposeWorkspaceElements(g);
+    if (halo_ws) {
+      if (!halo) CD_INVALID_USAGE("halo_extents argument cannot be null");
+      *halo_ws = haloWorkspaceElements(g, gridIndexOfRank(g, rank), axis, halo);
+    }
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
 cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDesc_t gd, cudecompExtCounters_t* out) {
   try {
     if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");

@@ -80,6 +80,17 @@ cudecompResult_t cudecompExtPlanHalo(const cudecompExtGridSpec_t* grid, int32_t 
                                      const int32_t halo_extents[], const bool halo_periods[], int32_t dim,
                                      const int32_t padding[], int32_t force_packed, cudecompExtHaloPlan_t* plan);
 
+/* Stateless geometry queries on a grid spec (no handle, no communicator): what cudecompGetPencilInfo,
+ * cudecompGetShiftedRank, cudecompGetTransposeWorkspaceSize and cudecompGetHaloWorkspaceSize would answer on `rank`. */
+cudecompResult_t cudecompExtPencilInfo(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis,
+                                       const int32_t halo_extents[], const int32_t padding[],
+                                       cudecompPencilInfo_t* pencil_info);
+cudecompResult_t cudecompExtShiftedRank(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis, int32_t dim,
+                                        int32_t displacement, bool periodic, int32_t* shifted_rank);
+cudecompResult_t cudecompExtWorkspaceSizes(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis,
+                                           const int32_t halo_extents[], int64_t* transpose_workspace,
+                                           int64_t* halo_workspace);
+
 /* Averages over the retained samples (CUDECOMP_PERFORMANCE_REPORT_SAMPLES, all configurations) of one transpose op,
  * recorded when CUDECOMP_ENABLE_PERFORMANCE_REPORT=1 was set at cudecompInit (0 calls otherwise).  Synchronises the device.  exchange_ms is the all-to-all
  * (including host-side ordering for the host-ordered transports); per-peer pipelined backends report the

@@ -149,6 +149,11 @@ def simulate_halos(d, axis, halo, periods, padding, force_packed):
             assert rc != orc.OK and e.code == rc, "product refused (%d) what the oracle accepts (%d)" % (e.code, rc)
             return False
         assert rc == orc.OK, "oracle refused what the product accepts"
+        if any(pl.kind == 1 for pl in plans) and halo[dim] > d["gdims"][dim]:
+            # periodic self copy of a halo wider than the whole (single-rank) dimension: source and destination of
+            # the two wrap copies overlap, in the reference too (halo.h:165-193 issues both in one kernel) -- the
+            # result is whatever the hardware's ordering makes it, so there is nothing to compare
+            return None
         for r in range(n):
             bufs = [data[r], data[r], work[r]]
             if plans[r].kind != 0:
@@ -183,7 +188,8 @@ def simulate_halos(d, axis, halo, periods, padding, force_packed):
 @given(d=decompositions(), axis=st.integers(0, 2), halo=small3, periods=st.tuples(st.booleans(), st.booleans(), st.booleans()),
        padding=small3, force_packed=st.booleans())
 def test_halo_plans_random_decompositions(d, axis, halo, periods, padding, force_packed):
-    simulate_halos(d, axis, halo, periods, padding, force_packed)
+    from hypothesis import assume
+    assume(simulate_halos(d, axis, halo, periods, padding, force_packed) is not None)
 
 
 def test_halo_wider_than_the_neighbours_slab_is_refused_like_the_oracle():
@@ -200,3 +206,33 @@ def test_empty_pencils_are_not_supported():
     with pytest.raises(cd.CudecompError) as e:
         cd.cudecompExtPlanHalo(spec, 0, 1, (1, 1, 1), (True, True, True), 0)
     assert e.value.code == 2
+
+
+@settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+@given(d=decompositions(max_ranks=24), halo=small3, padding=small3, disp=st.integers(-3, 3), periodic=st.booleans())
+def test_index_maps_random_decompositions(d, halo, padding, disp, periodic):
+    """Pencil geometry, neighbour ranks and workspace sizes of EVERY rank of random decompositions (the functions
+    behind cudecompGetPencilInfo / GetShiftedRank / Get*WorkspaceSize) against the oracle, whose index maps are pinned
+    to the reference's golden vectors."""
+    spec, g = _grids(d)
+    for rank in range(g.nranks):
+        for axis in range(3):
+            got = cd.cudecompExtPencilInfo(spec, rank, axis, halo, padding).as_dict()
+            assert got == g.pencil_info(rank, axis, halo, padding).as_dict(), (rank, axis)
+            tws, hws = cd.cudecompExtWorkspaceSizes(spec, rank, axis, halo)
+            assert tws == g.transpose_workspace_size() and hws == g.halo_workspace_size(rank, axis, halo), (rank, axis)
+            for dim in range(3):
+                assert cd.cudecompExtShiftedRank(spec, rank, axis, dim, disp, periodic) == \
+                    g.shifted_rank(rank, axis, dim, disp, periodic), (rank, axis, dim, disp, periodic)
+
+
+def test_index_maps_reject_bad_arguments():
+    spec = cd.make_grid_spec((8, 8, 8), (2, 2), ((0, 1, 2),) * 3)
+    for call in (lambda: cd.cudecompExtPencilInfo(spec, 4, 0), lambda: cd.cudecompExtPencilInfo(spec, 0, 3),
+                 lambda: cd.cudecompExtPencilInfo(spec, 0, 0, (-1, 0, 0)), lambda: cd.cudecompExtShiftedRank(spec, 0, 0, 3, 1, False)):
+        with pytest.raises(cd.CudecompError) as e:
+            call()
+        assert e.value.code == 1  # CUDECOMP_RESULT_INVALID_USAGE
+    bad = cd.make_grid_spec((8, 8, 8), (2, 2), ((0, 1, 1), (0, 1, 2), (0, 1, 2)))
+    with pytest.raises(cd.CudecompError):
+        cd.cudecompExtPencilInfo(bad, 0, 0)
