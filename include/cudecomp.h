@@ -170,34 +170,40 @@ typedef struct {
 } cudecompPencilInfo_t;
 
 /* ---- library / grid-descriptor lifetime --------------------------------------------------- */
+/* replaces: reference include/cudecomp.h:249-268 (cudecompInit, cudecompInit_F, cudecompFinalize), src/cudecomp.cc:903-1035 */
 cudecompResult_t cudecompInit(cudecompHandle_t* handle, MPI_Comm mpi_comm);
 cudecompResult_t cudecompInit_F(cudecompHandle_t* handle, MPI_Fint mpi_comm_f);
 cudecompResult_t cudecompFinalize(cudecompHandle_t handle);
 
+/* replaces: reference cudecomp.h:272-313 (create / destroy; config is in/out), src/cudecomp.cc:1039-1283 */
 cudecompResult_t cudecompGridDescCreateVersioned(cudecompHandle_t handle, cudecompGridDesc_t* grid_desc,
                                                  cudecompGridDescConfig_t* config, int64_t config_struct_size,
                                                  int32_t config_version,
                                                  const cudecompGridDescAutotuneOptions_t* options,
                                                  int64_t options_struct_size, int32_t options_version);
 cudecompResult_t cudecompGridDescDestroy(cudecompHandle_t handle, cudecompGridDesc_t grid_desc);
+/* replaces: reference cudecomp.h:317-354 (defaults), src/cudecomp.cc:1285-1313 */
 cudecompResult_t cudecompGridDescConfigSetDefaultsVersioned(cudecompGridDescConfig_t* config, int64_t struct_size,
                                                             int32_t version);
 cudecompResult_t cudecompGridDescAutotuneOptionsSetDefaultsVersioned(cudecompGridDescAutotuneOptions_t* options,
                                                                      int64_t struct_size, int32_t version);
+/* replaces: reference cudecomp.h:484-501, src/cudecomp.cc:1381-1409 */
 cudecompResult_t cudecompGetGridDescConfigVersioned(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
                                                     cudecompGridDescConfig_t* config, int64_t struct_size,
                                                     int32_t version);
 
 /* ---- queries ------------------------------------------------------------------------------ */
+/* replaces: reference cudecomp.h:358-388 (pencil info), src/cudecomp.cc:1317-1379 */
 cudecompResult_t cudecompGetPencilInfoVersioned(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
                                                 cudecompPencilInfo_t* pencil_info, int64_t pencil_info_struct_size,
                                                 int32_t pencil_info_version, int32_t axis, const int32_t halo_extents[],
                                                 const int32_t padding[]);
-/* sizes are in ELEMENTS of the dtype used later */
+/* sizes are in ELEMENTS of the dtype used later; replaces: reference cudecomp.h:401-421, src/cudecomp.cc:1411-1459 */
 cudecompResult_t cudecompGetTransposeWorkspaceSize(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
                                                    int64_t* workspace_size);
 cudecompResult_t cudecompGetHaloWorkspaceSize(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t axis,
                                               const int32_t halo_extents[], int64_t* workspace_size);
+/* replaces: reference cudecomp.h:430, 472-481, 517 (dtype size, backend names, shifted rank), src/cudecomp.cc:1669-1755 */
 cudecompResult_t cudecompGetDataTypeSize(cudecompDataType_t dtype, int64_t* dtype_size);
 cudecompResult_t cudecompGetShiftedRank(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t axis,
                                         int32_t dim, int32_t displacement, bool periodic, int32_t* shifted_rank);
@@ -205,11 +211,14 @@ const char* cudecompTransposeCommBackendToString(cudecompTransposeCommBackend_t 
 const char* cudecompHaloCommBackendToString(cudecompHaloCommBackend_t comm_backend);
 
 /* ---- workspace allocation (collective) ------------------------------------------------------ */
+/* replaces: reference cudecomp.h:447-462, src/cudecomp.cc:1461-1667 */
 cudecompResult_t cudecompMalloc(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void** buffer,
                                 size_t buffer_size_bytes);
 cudecompResult_t cudecompFree(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* buffer);
 
 /* ---- transposes (collective) ---------------------------------------------------------------- */
+/* replaces: reference cudecomp.h:545-635, src/cudecomp.cc:1757-1919 -> include/internal/transpose.h:196-953.
+ * NULL halo / padding arrays mean zeros; input == output means in place. */
 cudecompResult_t cudecompTransposeXToY(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* output,
                                        void* work, cudecompDataType_t dtype, const int32_t input_halo_extents[],
                                        const int32_t output_halo_extents[], const int32_t input_padding[],
@@ -228,6 +237,7 @@ cudecompResult_t cudecompTransposeYToX(cudecompHandle_t handle, cudecompGridDesc
                                        const int32_t output_padding[], hipStream_t stream);
 
 /* ---- halo updates (collective); dim = global axis whose halos are exchanged ------------------ */
+/* replaces: reference cudecomp.h:661-717, src/cudecomp.cc:1921-2045 -> include/internal/halo.h:41-348 */
 cudecompResult_t cudecompUpdateHalosX(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, void* input, void* work,
                                       cudecompDataType_t dtype, const int32_t halo_extents[], const bool halo_periods[],
                                       int32_t dim, const int32_t padding[], hipStream_t stream);
