@@ -304,7 +304,10 @@ def main():
                     "kernel": "transpose_kernel<8,2,64,64,2,true>" if args.layout == "contiguous" else "rows_kernel<16,true>",
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4)}
         out = {
-            "metric": "transpose cycle (X->Y->Z->Y->X) effective bandwidth, %d^3 fp64" % n,
+            # BASELINE.json's metric, verbatim at its size; `value` is the effective GB/s (4 x global bytes / cycle time),
+            # `ms_per_step` the cycle wall time, `xgmi` the bisection fraction (N > 1)
+            "metric": ("transpose cycle wall time + effective GB/s (vs xGMI bisection), 1024\u00b3 fp64" if n == 1024 else
+                       "transpose cycle wall time + effective GB/s (vs xGMI bisection), %d^3 fp64" % n),
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
