@@ -58,6 +58,7 @@ struct cudecompHandle {
   std::string performance_report_write_dir;   // CSV output directory ("" = none)
   bool col_major_env_warned = false;
   bool ipc_warned = false;
+  bool halo_overlap_disable = false;  // CUDECOMP_DISABLE_HALO_OVERLAP=1
 
   cudecomp::KernelTuning tuning;
   int next_barrier_slot = 0;  // communicator slots are handed out round-robin, identically on every rank

@@ -656,4 +656,91 @@ void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange&
   pc.barrier(ci);
 }
 
+// ------------------------------------------------------------------------------------------------
+// packed halo update, pack / exchange / unpack overlapped
+// ------------------------------------------------------------------------------------------------
+bool haloExchangePackedOverlapped(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x, const HaloPlan& plan,
+                                  void* const bufs[3], int es, cudecompHaloCommBackend_t backend, hipStream_t stream) {
+  const bool rccl = haloBackendIsRccl(backend);
+#ifdef CUDECOMP_WITH_MPI
+  if (!rccl && haloBackendIsMpi(backend) && h->boot->nativeComm()) return false;  // MPI flavour: plain path
+#endif
+  auto moveOf = [](const std::vector<Move3D>& v, int tag) -> const Move3D* {
+    for (const Move3D& m : v)
+      if (m.peer == tag) return &m;
+    return nullptr;
+  };
+  if ((int)gd->events.size() < 4) {
+    const size_t old = gd->events.size();
+    gd->events.resize(4);
+    for (size_t i = old; i < gd->events.size(); ++i)
+      CD_CHECK_HIP(hipEventCreateWithFlags(&gd->events[i], hipEventDisableTiming));
+  }
+  hipEvent_t* packed = &gd->events[0];   // [face]
+  hipEvent_t* arrived = &gd->events[2];  // [direction]
+
+  if (rccl) {
+    if (!h->rccl) CD_INTERNAL_ERROR("RCCL communicator was not created for this grid descriptor");
+    ncclComm_t comm = h->rccl->comm();
+    if (h->streams.empty()) {
+      int lo = 0, hi = 0;
+      CD_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      hipStream_t s;
+      CD_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+      h->streams.push_back(s);
+    }
+    hipStream_t side = h->streams[0];
+    // Direction d moves data towards neighbour d: my face d goes there, and from the OTHER side arrives that
+    // neighbour's face d, which fills my halo slot 1-d.  Everybody's direction-d group holds exactly the matching
+    // send / receive pairs, so the two groups cannot wait on each other around a periodic ring.
+    for (int d = 0; d < 2; ++d) {
+      if (const Move3D* m = moveOf(plan.pre, d)) launchMoves(m, 1, bufs, es, stream, &h->tuning);
+      CD_CHECK_HIP(hipEventRecord(packed[d], stream));
+    }
+    for (int d = 0; d < 2; ++d) {
+      CD_CHECK_HIP(hipStreamWaitEvent(side, packed[d], 0));
+      if (x.neighbor[d] != -1 || x.neighbor[1 - d] != -1) {
+        CD_CHECK_RCCL(ncclGroupStart());
+        if (x.neighbor[d] != -1)
+          CD_CHECK_RCCL(ncclSend(x.send + x.send_off[d], (size_t)x.bytes, ncclInt8, x.neighbor[d], comm, side));
+        if (x.neighbor[1 - d] != -1)
+          CD_CHECK_RCCL(ncclRecv(x.recv + x.recv_off[1 - d], (size_t)x.bytes, ncclInt8, x.neighbor[1 - d], comm, side));
+        CD_CHECK_RCCL(ncclGroupEnd());
+      }
+      CD_CHECK_HIP(hipEventRecord(arrived[d], side));
+      CD_CHECK_HIP(hipStreamWaitEvent(stream, arrived[d], 0));
+      if (const Move3D* m = moveOf(plan.post, 1 - d)) launchMoves(m, 1, bufs, es, stream, &h->tuning);
+    }
+    return true;
+  }
+
+  // one-sided transport, host-ordered: the barrier ("every receive slot is free") overlaps the packs, each face's
+  // copy waits for its own pack only
+  if (!h->peer) CD_INTERNAL_ERROR("peer transport was not created for this grid descriptor");
+  PeerContext& pc = *h->peer;
+  cudecompCommInfo& ci = gd->comm(x.comm_axis);
+  if (!gd->entry_event) CD_CHECK_HIP(hipEventCreateWithFlags(&gd->entry_event, hipEventDisableTiming));
+  CD_CHECK_HIP(hipEventRecord(gd->entry_event, stream));
+  for (int i = 0; i < 2; ++i) {
+    if (const Move3D* m = moveOf(plan.pre, i)) launchMoves(m, 1, bufs, es, stream, &h->tuning);
+    CD_CHECK_HIP(hipEventRecord(packed[i], stream));
+  }
+  char* remote[2] = {nullptr, nullptr};
+  if (pc.anyUnregistered(x.recv)) (void)pc.translate(x.recv, h->rank);  // registration is collective: do it first
+  for (int i = 0; i < 2; ++i)
+    if (x.neighbor[i] != -1) remote[i] = pc.translate(x.recv, x.neighbor[i]) + x.remote_off[i];
+  CD_CHECK_HIP(hipEventSynchronize(gd->entry_event));  // my previous use of the receive slots is over
+  pc.barrier(ci);
+  for (int i = 0; i < 2; ++i)
+    if (x.neighbor[i] != -1) {
+      CD_CHECK_HIP(hipStreamWaitEvent(pc.copyStream(i), packed[i], 0));
+      CD_CHECK_HIP(hipMemcpyAsync(remote[i], x.send + x.send_off[i], (size_t)x.bytes, hipMemcpyDeviceToDevice,
+                                  pc.copyStream(i)));
+    }
+  for (int i = 0; i < 2; ++i) CD_CHECK_HIP(hipStreamSynchronize(pc.copyStream(i)));
+  pc.barrier(ci);
+  launchMoves(plan.post.data(), (int)plan.post.size(), bufs, es, stream, &h->tuning);
+  return true;
+}
+
 }  // namespace cudecomp

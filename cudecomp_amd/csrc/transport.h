@@ -79,6 +79,12 @@ struct HaloExchange {
 };
 void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x,
                   cudecompHaloCommBackend_t backend, hipStream_t stream);
+// Packed halo update with the local phases overlapped with the exchange: the face packs are launched one by one (an
+// event each), every face starts travelling as soon as ITS pack is done while the other face is still being packed,
+// and (RCCL) a halo slot is unpacked while the other direction is still in flight.  Runs pack, exchange and unpack;
+// returns false if this backend has no overlapped variant (the caller then takes the plain path).
+bool haloExchangePackedOverlapped(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x, const HaloPlan& plan,
+                                  void* const bufs[3], int es, cudecompHaloCommBackend_t backend, hipStream_t stream);
 
 #ifdef CUDECOMP_WITH_MPI
 // bootstrap_mpi.cc

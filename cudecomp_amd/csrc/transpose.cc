@@ -259,6 +259,16 @@ void runHalo(cudecompHandle_t h, cudecompGridDesc_t gd, int axis, void* input, v
   }
   x.bytes = plan.face_elements * es;
   x.comm_axis = plan.comm_axis;
+  // packed faces: pack, exchange and unpack overlap face by face (env CUDECOMP_DISABLE_HALO_OVERLAP=1 restores the
+  // plain pack -> exchange -> unpack sequence of the reference, halo.h:200-260)
+  if (plan.kind == HaloPlan::PACKED && !h->halo_overlap_disable) {
+    perfMark(pev, 1, stream);
+    if (haloExchangePackedOverlapped(h, gd, x, plan, bufs, es, backend, stream)) {
+      perfMark(pev, 2, stream);
+      perfMark(pev, 3, stream);
+      return;
+    }
+  }
   if (plan.kind == HaloPlan::PACKED) launchMoves(plan.pre.data(), (int)plan.pre.size(), bufs, es, stream, &h->tuning);
   perfMark(pev, 1, stream);
   haloExchange(h, gd, x, backend, stream);

@@ -137,8 +137,8 @@ def test_sweep_eight_ranks():
                                  {"CUDECOMP_ENABLE_PERFORMANCE_REPORT": "1", "CUDECOMP_PERFORMANCE_REPORT_DETAIL": "2",
                                   "CUDECOMP_PERFORMANCE_REPORT_WARMUP_SAMPLES": "0"},
                                  {"CUDECOMP_DISABLE_STREAMING_ACCESS": "1", "CUDECOMP_TILE_WALK": "0"},
-                                 {"CUDECOMP_FORCE_GENERIC_KERNELS": "1"}],
-                         ids=["graphs", "performance_report", "cached_access_i_first", "generic_kernels"])
+                                 {"CUDECOMP_FORCE_GENERIC_KERNELS": "1"}, {"CUDECOMP_DISABLE_HALO_OVERLAP": "1"}],
+                         ids=["graphs", "performance_report", "cached_access_i_first", "generic_kernels", "plain_halo_sequence"])
 def test_sweep_library_switches_do_not_change_results(env):
     """Environment switches of the library (graph capture of the pipelined pack loop, the performance report, kernel
     tuning / debug switches) on a slice of the base sweep: results stay exact."""
@@ -147,5 +147,10 @@ def test_sweep_library_switches_do_not_change_results(env):
     lines += [_tcase(pr, pc, 2, hx="1 1 1", hy="1 1 1", hz="1 1 1", px="1 1 1", pz="1 1 1",
                      extra="--acx 1 --acy 1 --acz 1") for pr, pc in PDIMS]
     _run("transpose_test_R64", 4, lines, dict(env))
-    hl = [_hcase(pr, pc, 1, ax, h=(1, 2, 1), pad=(1, 0, 0)) for (pr, pc), ax in itertools.product(PDIMS, (0, 1, 2))]
-    _run("halo_test_R64", 4, hl, dict(env))
+    hl = [_hcase(pr, pc, b, ax, h=(1, 2, 1), pad=(1, 0, 0)) for (pr, pc), ax, b in itertools.product(PDIMS, (0, 1, 2), (1, 3))]
+    henv = dict(env)
+    if os.path.exists(SHIM):
+        henv["LD_PRELOAD"] = SHIM  # backend 3 (RCCL code path) with four ranks on one GPU
+    else:
+        hl = [l for l in hl if "--backend 3" not in l]
+    _run("halo_test_R64", 4, hl, henv)
