@@ -334,6 +334,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->performance_report_warmup_samples = envInt("CUDECOMP_PERFORMANCE_REPORT_WARMUP_SAMPLES", 0, 1 << 30, 3);
     if (const char* v = std::getenv("CUDECOMP_PERFORMANCE_REPORT_WRITE_DIR")) h->performance_report_write_dir = v;
     h->halo_overlap_disable = envIsOne("CUDECOMP_DISABLE_HALO_OVERLAP");
+    h->halo_overlap_force = envIsOne("CUDECOMP_FORCE_HALO_OVERLAP");
     h->tuning.no_streaming = envIsOne("CUDECOMP_DISABLE_STREAMING_ACCESS");
     if (const char* v = std::getenv("CUDECOMP_TILE_WALK")) h->tuning.walk_order = (int)std::strtol(v, nullptr, 10);  // tuning aid
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))

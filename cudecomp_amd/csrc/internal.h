@@ -59,6 +59,7 @@ struct cudecompHandle {
   bool col_major_env_warned = false;
   bool ipc_warned = false;
   bool halo_overlap_disable = false;  // CUDECOMP_DISABLE_HALO_OVERLAP=1
+  bool halo_overlap_force = false;    // CUDECOMP_FORCE_HALO_OVERLAP=1: also for faces below the size threshold (tests)
 
   cudecomp::KernelTuning tuning;
   int next_barrier_slot = 0;  // communicator slots are handed out round-robin, identically on every rank

@@ -659,6 +659,8 @@ void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange&
 // ------------------------------------------------------------------------------------------------
 // packed halo update, pack / exchange / unpack overlapped
 // ------------------------------------------------------------------------------------------------
+constexpr i64 kHaloOverlapMinBytes = 1 << 20;
+
 bool haloExchangePackedOverlapped(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x, const HaloPlan& plan,
                                   void* const bufs[3], int es, cudecompHaloCommBackend_t backend, hipStream_t stream) {
   const bool rccl = haloBackendIsRccl(backend);
@@ -679,6 +681,8 @@ bool haloExchangePackedOverlapped(cudecompHandle_t h, cudecompGridDesc_t gd, con
   hipEvent_t* packed = &gd->events[0];   // [face]
   hipEvent_t* arrived = &gd->events[2];  // [direction]
 
+  // two RCCL groups cost two collective launches: worth it only when a face takes longer to move than to launch
+  if (rccl && x.bytes < kHaloOverlapMinBytes && !h->halo_overlap_force) return false;
   if (rccl) {
     if (!h->rccl) CD_INTERNAL_ERROR("RCCL communicator was not created for this grid descriptor");
     ncclComm_t comm = h->rccl->comm();

@@ -137,8 +137,10 @@ def test_sweep_eight_ranks():
                                  {"CUDECOMP_ENABLE_PERFORMANCE_REPORT": "1", "CUDECOMP_PERFORMANCE_REPORT_DETAIL": "2",
                                   "CUDECOMP_PERFORMANCE_REPORT_WARMUP_SAMPLES": "0"},
                                  {"CUDECOMP_DISABLE_STREAMING_ACCESS": "1", "CUDECOMP_TILE_WALK": "0"},
-                                 {"CUDECOMP_FORCE_GENERIC_KERNELS": "1"}, {"CUDECOMP_DISABLE_HALO_OVERLAP": "1"}],
-                         ids=["graphs", "performance_report", "cached_access_i_first", "generic_kernels", "plain_halo_sequence"])
+                                 {"CUDECOMP_FORCE_GENERIC_KERNELS": "1"}, {"CUDECOMP_DISABLE_HALO_OVERLAP": "1"},
+                                 {"CUDECOMP_FORCE_HALO_OVERLAP": "1"}],
+                         ids=["graphs", "performance_report", "cached_access_i_first", "generic_kernels", "plain_halo_sequence",
+                              "overlapped_halo_any_size"])
 def test_sweep_library_switches_do_not_change_results(env):
     """Environment switches of the library (graph capture of the pipelined pack loop, the performance report, kernel
     tuning / debug switches) on a slice of the base sweep: results stay exact."""
