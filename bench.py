@@ -74,7 +74,12 @@ class c_stdout_to_stderr:
 
 
 def cpu_baseline(sample, layout):
-    """Oracle timed on this host: one X->Y->Z->Y->X cycle of a sample^3 fp64 array, 1x1 grid, same layout."""
+    """The CPU path timed on this host's cores, on a sample^3 fp64 array with the same layout: the host-MPI path
+    (oracle/cpu_mpi_cycle: pack -> MPI_Alltoallv -> unpack with one rank per core, up to 8) when an MPI installation
+    is present, else the single-process oracle on one core."""
+    mpi = cpu_baseline_mpi(sample, layout)
+    if mpi is not None:
+        return mpi
     import numpy as np
     from oracle import oracle as orc
     ac = (1, 1, 1) if layout == "contiguous" else (0, 0, 0)
@@ -91,6 +96,39 @@ def cpu_baseline(sample, layout):
     return {"value": round(4 * n * 8 / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "sample": "%d^3 fp64 X->Y->Z->Y->X cycle, 1x1 grid, %s layout, out-of-place, %.1f s on one core"
                       % (sample, layout, dt)}
+
+
+def cpu_baseline_mpi(sample, layout):
+    """mpirun -np R oracle/cpu_mpi_cycle ... ; None if there is no MPI here or anything goes wrong."""
+    import shutil
+    import subprocess
+    try:
+        mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+        if not os.path.exists(mpirun) or not os.path.exists("/opt/conda/include/mpi.h"):
+            return None
+        exe = os.path.join(ROOT, "oracle", "cpu_mpi_cycle")
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "cpu_mpi_cycle"], stdout=sys.stderr,
+                                  stderr=sys.stderr)
+        cores = os.cpu_count() or 1
+        ranks = 8 if cores >= 8 else 4 if cores >= 4 else 2 if cores >= 2 else 1
+        pr, pc = (2, ranks // 2) if ranks >= 4 else (1, ranks)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        t0 = time.perf_counter()
+        out = subprocess.run([mpirun, "-np", str(ranks), exe, str(sample), str(pr), str(pc),
+                              "1" if layout == "contiguous" else "0", "1", "3"], env=env, capture_output=True, text=True,
+                             timeout=240)
+        dt = time.perf_counter() - t0
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        if not rec["round_trip_ok"]:
+            return None
+        return {"value": round(rec["gbps"], 4), "unit": "GB/s", "cores": ranks, "kind": "port",
+                "sample": "%d^3 fp64 X->Y->Z->Y->X cycle on host memory, %d MPI ranks (%dx%d grid, one per core; MPICH "
+                          "shared-memory MPI_Alltoallv), %s layout, out-of-place, %.3f s per cycle, 1 warm-up + 3 timed, "
+                          "%.1f s in total" % (sample, ranks, pr, pc, layout, rec["cycle_s"], dt)}
+    except Exception as e:  # the baseline is a courtesy number: never let it take the benchmark down
+        sys.stderr.write("bench.py: host-MPI CPU baseline unavailable (%s); using the single-core oracle\n" % e)
+        return None
 
 
 def main():

@@ -524,12 +524,12 @@ static void transpose_unpack(const tcfg_t* t, tctx_t* c) {
   }
 }
 
-int orc_transpose(const orc_grid_t* g, int ax, int dir, int es, void* const* in, void* const* out, void* const* work,
-                  const int32_t in_halo[3], const int32_t out_halo[3], const int32_t in_pad[3],
-                  const int32_t out_pad[3], int pipelined) {
+/* configuration shared by all ranks of one transpose call (transpose.h:222-259) */
+static int transpose_setup(const orc_grid_t* g, int ax, int dir, int es, const int32_t in_halo[3],
+                           const int32_t out_halo[3], const int32_t in_pad[3], const int32_t out_pad[3], int pipelined,
+                           tcfg_t* tp, int flags[3]) {
   if (es != 4 && es != 8 && es != 16) return ORC_INVALID_USAGE;
   if (ax < 0 || ax > 2 || dir == 0) return ORC_INVALID_USAGE;
-  const int nranks = orc_nranks(g);
   tcfg_t t;
   memset(&t, 0, sizeof(t));
   t.es = es;
@@ -546,6 +546,9 @@ int orc_transpose(const orc_grid_t* g, int ax, int dir, int es, void* const* in,
     if (t.out_halo[i] || t.out_pad[i]) output_hp = 1;
     if (t.in_halo[i] != t.out_halo[i] || t.in_pad[i] != t.out_pad[i]) hp_equal = 0;
   }
+  flags[0] = input_hp;
+  flags[1] = output_hp;
+  flags[2] = hp_equal;
 
   /* axes and communicator (transpose.h:222-245) */
   int fwd = dir > 0;
@@ -561,72 +564,93 @@ int orc_transpose(const orc_grid_t* g, int ax, int dir, int es, void* const* in,
     t.offsets_b[i + 1] = t.offsets_b[i] + t.splits_b[i];
   }
   if (has_empty_pencils(g, t.ax_a) || has_empty_pencils(g, t.ax_b)) return ORC_NOT_SUPPORTED; /* :257-259 */
+  /* the two memory orders are the same on every rank */
+  orc_pinfo_t a0, b0;
+  int rc;
+  if ((rc = orc_pencil_info(g, 0, t.ax_a, NULL, NULL, &a0))) return rc;
+  if ((rc = orc_pencil_info(g, 0, t.ax_b, NULL, NULL, &b0))) return rc;
+  t.orders_equal = 1;
+  for (int i = 0; i < 3; ++i)
+    if (a0.order[i] != b0.order[i]) t.orders_equal = 0;
+  *tp = t;
+  return ORC_OK;
+}
 
-  tctx_t* ctx = (tctx_t*)calloc((size_t)nranks, sizeof(tctx_t));
-  if (!ctx) return ORC_NOT_SUPPORTED;
-  int rc = ORC_OK;
-  for (int r = 0; r < nranks && rc == ORC_OK; ++r) {
-    tctx_t* c = &ctx[r];
-    if ((rc = orc_pencil_info(g, r, t.ax_a, NULL, NULL, &c->a))) break;
-    if ((rc = orc_pencil_info(g, r, t.ax_a, t.in_halo, t.in_pad, &c->ah))) break;
-    if ((rc = orc_pencil_info(g, r, t.ax_b, NULL, NULL, &c->b))) break;
-    if ((rc = orc_pencil_info(g, r, t.ax_b, t.out_halo, t.out_pad, &c->bh))) break;
-    shape_g(&c->a, c->sga);
-    shape_g(&c->ah, c->sgah);
-    shape_g(&c->b, c->sgb);
-    shape_g(&c->bh, c->sgbh);
-    int32_t pidx[2];
-    orc_pidx(g, r, pidx);
-    c->comm_rank = (t.comm_axis == 0) ? pidx[0] : pidx[1];
-    if (r == 0) {
-      t.orders_equal = 1;
-      for (int i = 0; i < 3; ++i)
-        if (c->a.order[i] != c->b.order[i]) t.orders_equal = 0;
-    }
-    int inplace = (in[r] == out[r]);
-    /* phase pointers (transpose.h:281-284) */
-    c->i1 = (char*)in[r];
-    c->o1 = (char*)work[r];
-    c->o2 = (char*)work[r] + orc_align_count(c->a.size, 256) * es;
-    c->o3 = (char*)out[r];
-    /* special cases (transpose.h:323-404) */
-    if (t.P == 1) {
-      if (t.orders_equal) {
-        if (inplace) {
-          if (hp_equal) c->done = 1; /* nothing to do */
-        } else {
-          c->o1 = c->o3;
-          c->direct_pack = 1;
-        }
-      } else if (!inplace) {
-        if (c->b.order[2] == t.ax_a) {
-          c->o1 = c->o3;
-          c->direct_transpose = 1;
-        } else {
-          c->o1 = c->i1;
-          c->o2 = c->i1;
-          c->direct_transpose = 1;
-        }
+/* one rank's pencils, phase pointers, special cases and exchange counts (transpose.h:281-421) */
+static int transpose_rank_context(const orc_grid_t* g, const tcfg_t* tp, const int flags[3], int r, void* in, void* out,
+                                  void* work, tctx_t* c) {
+  const tcfg_t t = *tp;
+  const int input_hp = flags[0], output_hp = flags[1], hp_equal = flags[2], es = t.es;
+  int rc;
+  if ((rc = orc_pencil_info(g, r, t.ax_a, NULL, NULL, &c->a))) return rc;
+  if ((rc = orc_pencil_info(g, r, t.ax_a, t.in_halo, t.in_pad, &c->ah))) return rc;
+  if ((rc = orc_pencil_info(g, r, t.ax_b, NULL, NULL, &c->b))) return rc;
+  if ((rc = orc_pencil_info(g, r, t.ax_b, t.out_halo, t.out_pad, &c->bh))) return rc;
+  shape_g(&c->a, c->sga);
+  shape_g(&c->ah, c->sgah);
+  shape_g(&c->b, c->sgb);
+  shape_g(&c->bh, c->sgbh);
+  int32_t pidx[2];
+  orc_pidx(g, r, pidx);
+  c->comm_rank = (t.comm_axis == 0) ? pidx[0] : pidx[1];
+  int inplace = (in == out);
+  /* phase pointers (transpose.h:281-284) */
+  c->i1 = (char*)in;
+  c->o1 = (char*)work;
+  c->o2 = (char*)work + orc_align_count(c->a.size, 256) * es;
+  c->o3 = (char*)out;
+  /* special cases (transpose.h:323-404) */
+  if (t.P == 1) {
+    if (t.orders_equal) {
+      if (inplace) {
+        if (hp_equal) c->done = 1; /* nothing to do */
+      } else {
+        c->o1 = c->o3;
+        c->direct_pack = 1;
       }
-    } else {
-      int enable = !(pipelined && inplace);
-      if (enable) {
-        if (c->a.order[2] == t.ax_a && !input_hp) {
-          c->o1 = c->i1;
-          c->o2 = (char*)work[r];
-        } else if (c->a.order[2] == t.ax_b && t.orders_equal && !output_hp) {
-          c->o2 = c->o3;
-        }
+    } else if (!inplace) {
+      if (c->b.order[2] == t.ax_a) {
+        c->o1 = c->o3;
+        c->direct_transpose = 1;
+      } else {
+        c->o1 = c->i1;
+        c->o2 = c->i1;
+        c->direct_transpose = 1;
       }
     }
-    /* counts / offsets (transpose.h:407-421) */
-    for (int i = 0; i < t.P; ++i) {
-      c->send_off[i] = t.offsets_a[i] * c->sga[t.ax_b] * c->sga[t.ax_c];
-      c->recv_off[i] = t.offsets_b[i] * c->sgb[t.ax_a] * c->sgb[t.ax_c];
-      c->send_cnt[i] = t.splits_a[i] * c->sga[t.ax_b] * c->sga[t.ax_c];
-      c->recv_cnt[i] = t.splits_b[i] * c->sgb[t.ax_a] * c->sgb[t.ax_c];
+  } else {
+    int enable = !(t.pipelined && inplace);
+    if (enable) {
+      if (c->a.order[2] == t.ax_a && !input_hp) {
+        c->o1 = c->i1;
+        c->o2 = (char*)work;
+      } else if (c->a.order[2] == t.ax_b && t.orders_equal && !output_hp) {
+        c->o2 = c->o3;
+      }
     }
   }
+  /* counts / offsets (transpose.h:407-421) */
+  for (int i = 0; i < t.P; ++i) {
+    c->send_off[i] = t.offsets_a[i] * c->sga[t.ax_b] * c->sga[t.ax_c];
+    c->recv_off[i] = t.offsets_b[i] * c->sgb[t.ax_a] * c->sgb[t.ax_c];
+    c->send_cnt[i] = t.splits_a[i] * c->sga[t.ax_b] * c->sga[t.ax_c];
+    c->recv_cnt[i] = t.splits_b[i] * c->sgb[t.ax_a] * c->sgb[t.ax_c];
+  }
+  return ORC_OK;
+}
+
+int orc_transpose(const orc_grid_t* g, int ax, int dir, int es, void* const* in, void* const* out, void* const* work,
+                  const int32_t in_halo[3], const int32_t out_halo[3], const int32_t in_pad[3],
+                  const int32_t out_pad[3], int pipelined) {
+  tcfg_t t;
+  int flags[3];
+  int rc = transpose_setup(g, ax, dir, es, in_halo, out_halo, in_pad, out_pad, pipelined, &t, flags);
+  if (rc != ORC_OK) return rc;
+  const int nranks = orc_nranks(g);
+  tctx_t* ctx = (tctx_t*)calloc((size_t)nranks, sizeof(tctx_t));
+  if (!ctx) return ORC_NOT_SUPPORTED;
+  for (int r = 0; r < nranks && rc == ORC_OK; ++r)
+    rc = transpose_rank_context(g, &t, flags, r, in[r], out[r], work[r], &ctx[r]);
 
   if (rc == ORC_OK) {
     for (int r = 0; r < nranks; ++r)
@@ -653,6 +677,29 @@ int orc_transpose(const orc_grid_t* g, int ax, int dir, int es, void* const* in,
   }
   free(ctx);
   return rc;
+}
+
+/* One rank of a transpose with the exchange delegated to the caller (e.g. MPI_Alltoallv over host memory: the
+ * "host-MPI CPU path" used as the CPU baseline, oracle/cpu_mpi_cycle.c).  Same pack / unpack code as above. */
+int orc_transpose_rank(const orc_grid_t* g, int rank, int ax, int dir, int es, void* in, void* out, void* work,
+                       const int32_t in_halo[3], const int32_t out_halo[3], const int32_t in_pad[3],
+                       const int32_t out_pad[3], int pipelined, orc_exchange_fn exchange, void* user) {
+  tcfg_t t;
+  int flags[3];
+  int rc = transpose_setup(g, ax, dir, es, in_halo, out_halo, in_pad, out_pad, pipelined, &t, flags);
+  if (rc != ORC_OK) return rc;
+  if (rank < 0 || rank >= orc_nranks(g)) return ORC_INVALID_USAGE;
+  tctx_t c;
+  memset(&c, 0, sizeof(c));
+  if ((rc = transpose_rank_context(g, &t, flags, rank, in, out, work, &c))) return rc;
+  if (c.done) return ORC_OK;
+  transpose_pack(&t, &c);
+  if (t.P > 1) {
+    if (!exchange) return ORC_INVALID_USAGE;
+    exchange(user, c.o1, c.send_cnt, c.send_off, c.o2, c.recv_cnt, c.recv_off, t.P, t.comm_axis, c.comm_rank, es);
+  }
+  transpose_unpack(&t, &c);
+  return ORC_OK;
 }
 
 /* ------------------------------------------------------------------------------------------ */

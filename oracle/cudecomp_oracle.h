@@ -92,6 +92,15 @@ void orc_fill_halo_reference(const orc_pinfo_t* p, const int32_t gdims[3], const
 /* 0 if equal (interior_only: ignore halo/padding cells), else 1 + index of the first mismatch. */
 int64_t orc_compare_pencil(const orc_pinfo_t* p, int es, const void* expected, const void* actual, int interior_only);
 
+/* exchange callback of orc_transpose_rank: chunk d of `send` (send_cnt[d] elements at send_off[d]) goes to member d
+ * of the row (comm_axis 1) / column (0) communicator, chunk s of `recv` arrives from member s; counts in elements */
+typedef void (*orc_exchange_fn)(void* user, const char* send, const int64_t* send_cnt, const int64_t* send_off, char* recv,
+                                const int64_t* recv_cnt, const int64_t* recv_off, int nmembers, int comm_axis,
+                                int comm_rank, int es);
+int orc_transpose_rank(const orc_grid_t* g, int rank, int ax, int dir, int es, void* in, void* out, void* work,
+                       const int32_t in_halo[3], const int32_t out_halo[3], const int32_t in_pad[3],
+                       const int32_t out_pad[3], int pipelined, orc_exchange_fn exchange, void* user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,23 @@ def test_axis_contiguous_combinations():
         for oop in (True, False):
             ok, msg = R.run_transpose_cycle(g, 2, z, z, oop)
             assert ok, (ac, msg)
+
+
+@pytest.mark.parametrize("ranks,pr,pc,contiguous", [(1, 1, 1, 1), (4, 2, 2, 1), (4, 1, 4, 0), (6, 3, 2, 1), (8, 2, 4, 0)])
+def test_host_mpi_cpu_path_round_trip(ranks, pr, pc, contiguous):
+    """oracle/cpu_mpi_cycle (the host-MPI CPU baseline of bench.py): the oracle's pack / unpack around a real
+    MPI_Alltoallv between processes must return every rank's X pencil after the four hops."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+    if not os.path.exists(mpirun) or not os.path.exists("/opt/conda/include/mpi.h"):
+        pytest.skip("no MPI installation in this image")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "cpu_mpi_cycle"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([mpirun, "-np", str(ranks), os.path.join(root, "oracle", "cpu_mpi_cycle"), "30", str(pr), str(pc),
+                          str(contiguous), "0", "1"], env=env, capture_output=True, text=True, timeout=120)
+    rec = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
+    assert out.returncode == 0 and rec["round_trip_ok"] and rec["ranks"] == ranks, out.stdout + out.stderr
