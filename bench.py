@@ -75,7 +75,7 @@ class c_stdout_to_stderr:
 
 def cpu_baseline(sample, layout):
     """The CPU path timed on this host's cores, on a sample^3 fp64 array with the same layout: the host-MPI path
-    (oracle/cpu_mpi_cycle: pack -> MPI_Alltoallv -> unpack with one rank per core, up to 8) when an MPI installation
+    (oracle/cpu_mpi_cycle: pack -> MPI_Alltoallv -> unpack with one rank per core, up to 64) when an MPI installation
     is present, else the single-process oracle on one core."""
     mpi = cpu_baseline_mpi(sample, layout)
     if mpi is not None:
@@ -111,8 +111,14 @@ def cpu_baseline_mpi(sample, layout):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "cpu_mpi_cycle"], stdout=sys.stderr,
                                   stderr=sys.stderr)
         cores = os.cpu_count() or 1
-        ranks = 8 if cores >= 8 else 4 if cores >= 4 else 2 if cores >= 2 else 1
-        pr, pc = (2, ranks // 2) if ranks >= 4 else (1, ranks)
+        # one rank per core, up to 64 (power of two, near-square process grid)
+        ranks = 1
+        while ranks * 2 <= min(cores, 64):
+            ranks *= 2
+        pr = 1
+        while pr * pr * 2 <= ranks:
+            pr *= 2
+        pc = ranks // pr
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
         t0 = time.perf_counter()
         out = subprocess.run([mpirun, "-np", str(ranks), exe, str(sample), str(pr), str(pc),
