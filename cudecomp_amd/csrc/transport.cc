@@ -436,6 +436,8 @@ void rcclAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan&
   CD_CHECK_RCCL(ncclGroupEnd());
 }
 
+// (Copies into a peer's mapping use hipMemcpyDefault: source and destination may live on different devices and the
+// runtime picks the engine from the pointers.)
 // One-sided exchange.  Host-ordered: (1) my chunks are packed (stream sync), (2) everybody's are and
 // everybody's receive area is free (barrier), (3) P-1 concurrent xGMI copies, one stream per peer so that
 // every link / SDMA queue is busy, (4) all copies landed everywhere (sync + barrier).
@@ -455,7 +457,7 @@ void peerAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan&
     const int d = p.schedule_dst[j];
     if (p.send_cnt[d] == 0) continue;
     CD_CHECK_HIP(hipMemcpyAsync(remote[d], b.send + p.send_off[d] * es, (size_t)p.send_cnt[d] * es,
-                                hipMemcpyDeviceToDevice, pc.copyStream(j)));
+                                hipMemcpyDefault, pc.copyStream(j)));
   }
   for (int j = 0; j < ci.nranks; ++j) CD_CHECK_HIP(hipStreamSynchronize(pc.copyStream(j)));
   pc.barrier(ci);
@@ -535,7 +537,7 @@ void peerPipelinedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCo
     if (d != me) pc.waitFlag(pc.ready(slot, ci.global_ranks[d]), epoch, "receive area of the destination");
     if (plan.send_cnt[d])
       CD_CHECK_HIP(hipMemcpyAsync(remote[d], b.send + plan.send_off[d] * es, (size_t)plan.send_cnt[d] * es,
-                                  hipMemcpyDeviceToDevice, cs));
+                                  hipMemcpyDefault, cs));
     CD_CHECK_HIP(hipEventRecord(pc.copyEvent(j), cs));
   }
   for (int j = 0; j < P; ++j) {
@@ -650,7 +652,7 @@ void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange&
   pc.barrier(ci);
   for (int i = 0; i < 2; ++i)
     if (x.neighbor[i] != -1)
-      CD_CHECK_HIP(hipMemcpyAsync(remote[i], x.send + x.send_off[i], (size_t)x.bytes, hipMemcpyDeviceToDevice,
+      CD_CHECK_HIP(hipMemcpyAsync(remote[i], x.send + x.send_off[i], (size_t)x.bytes, hipMemcpyDefault,
                                   pc.copyStream(i)));
   for (int i = 0; i < 2; ++i) CD_CHECK_HIP(hipStreamSynchronize(pc.copyStream(i)));
   pc.barrier(ci);
@@ -738,7 +740,7 @@ bool haloExchangePackedOverlapped(cudecompHandle_t h, cudecompGridDesc_t gd, con
   for (int i = 0; i < 2; ++i)
     if (x.neighbor[i] != -1) {
       CD_CHECK_HIP(hipStreamWaitEvent(pc.copyStream(i), packed[i], 0));
-      CD_CHECK_HIP(hipMemcpyAsync(remote[i], x.send + x.send_off[i], (size_t)x.bytes, hipMemcpyDeviceToDevice,
+      CD_CHECK_HIP(hipMemcpyAsync(remote[i], x.send + x.send_off[i], (size_t)x.bytes, hipMemcpyDefault,
                                   pc.copyStream(i)));
     }
   for (int i = 0; i < 2; ++i) CD_CHECK_HIP(hipStreamSynchronize(pc.copyStream(i)));
