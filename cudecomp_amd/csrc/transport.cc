@@ -102,6 +102,7 @@ class PeerContext {
       unsigned long long bytes;
       int pid;
     };
+    enablePeerAccessOnce();
     // Failures are agreed on collectively (a rank that threw on its own would leave the others waiting in the
     // next collective): everybody tries, then everybody learns whether anybody failed.
     Wire mine{};
@@ -147,6 +148,24 @@ class PeerContext {
     }
     auto ins = regions_.emplace(r.base, std::move(r));
     return &ins.first->second;
+  }
+
+  // Best effort: a process that sees several GPUs (torchrun exposes all of them to every rank) turns on peer access
+  // from its device to the others, so kernels and copy engines may address IPC-mapped memory of any of them.
+  void enablePeerAccessOnce() {
+    if (peer_access_done_) return;
+    peer_access_done_ = true;
+    int dev = -1, count = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceCount(&count) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    for (int d = 0; d < count; ++d) {
+      int can = 0;
+      if (d == dev || hipDeviceCanAccessPeer(&can, dev, d) != hipSuccess || !can) continue;
+      (void)hipDeviceEnablePeerAccess(d, 0);  // "already enabled" is fine
+    }
+    (void)hipGetLastError();
   }
 
   // collective
@@ -309,6 +328,7 @@ class PeerContext {
   std::vector<hipStream_t> copy_streams_;
   std::vector<hipEvent_t> copy_events_;
   std::atomic<uint64_t>* flags_ = nullptr;
+  bool peer_access_done_ = false;
   char* board_ = nullptr;
   size_t board_bytes_ = 0;
 };
