@@ -347,6 +347,23 @@ def main():
                     "traffic": measured_traffic(args.layout) if n == 1024 else None,
                     "kernel": "transpose_kernel<8,2,64,64,2,true>" if args.layout == "contiguous" else "rows_kernel<16,true>",
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4)}
+            if args.layout == "contiguous" and not args.inplace:
+                # context for `frac`: what a plain copy of the same pencil reaches on this GPU right now (the library's
+                # row-copy kernel on the same buffers: X->Y of a 1x1 grid in the default layout), outside the timed region
+                gdc = cd.cudecompGridDescCreate(h, cd.make_config((n, n, n), (1, 1), axis_contiguous=(0, 0, 0)))
+                for _ in range(2):
+                    cd.cudecompTranspose("XToY", h, gdc, a.data_ptr(), b.data_ptr(), work, cd.DOUBLE, stream=stream)
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(5):
+                    cd.cudecompTranspose("XToY", h, gdc, a.data_ptr(), b.data_ptr(), work, cd.DOUBLE, stream=stream)
+                c1.record()
+                torch.cuda.synchronize()
+                copy_rate = alg_bytes / (c0.elapsed_time(c1) / 5 * 1e-3) / 1e9
+                cd.cudecompGridDescDestroy(h, gdc)
+                roof["copy_rate"] = {"achieved": round(copy_rate, 1), "unit": "GB/s", "kernel": "rows_kernel<16,true>",
+                                     "what": "dense copy of the same 8 GiB pencil, same buffers, measured in this run"}
+                roof["frac_of_copy_rate"] = round(achieved / copy_rate, 4)
         out = {
             # BASELINE.json's metric, verbatim at its size; `value` is the effective GB/s (4 x global bytes / cycle time),
             # `ms_per_step` the cycle wall time, `xgmi` the bisection fraction (N > 1)
