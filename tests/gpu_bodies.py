@@ -319,8 +319,13 @@ def repeated_cycle(rank, nranks, args):
         a.copy_(torch.from_numpy(init.view(np.uint8)))
         b.fill_(0x5A)
         cur, nxt = a, b
-        for op in cd.OPS:
+        for k, op in enumerate(cd.OPS):
             ai, ao = orc.OP_AXES[op]
+            if args.get("skew_ms"):
+                # ranks enter the collective at very different times, in an order that changes from call to call
+                import time
+                order = (rank + it + k) % nranks if (it + k) % 2 else (nranks - 1 - rank)
+                time.sleep(order * args["skew_ms"] * 1e-3)
             cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DTYPE_OF_KIND[kind], None, None,
                                  None, None, G.stream_ptr())
             torch.cuda.synchronize()
