@@ -73,18 +73,55 @@ def measured_traffic(layout):
 
 
 class c_stdout_to_stderr:
-    """Route C-level stdout (the library's autotune log) to stderr for the duration of the block."""
+    """Route C-level stdout (the library's autotune log) to stderr for the duration of the block; the text is kept in
+    `.text` so that the sweep's per-candidate results can be reported (parse_sweep)."""
 
     def __enter__(self):
+        import tempfile
         sys.stdout.flush()
         self.saved = os.dup(1)
-        os.dup2(2, 1)
+        self.tmp = tempfile.TemporaryFile(mode="w+b")
+        os.dup2(self.tmp.fileno(), 1)
+        self.text = ""
+        return self
 
     def __exit__(self, *exc):
         import ctypes
         ctypes.CDLL(None).fflush(None)
         os.dup2(self.saved, 1)
         os.close(self.saved)
+        self.tmp.seek(0)
+        self.text = self.tmp.read().decode(errors="replace")
+        self.tmp.close()
+        sys.stderr.write(self.text)
+        sys.stderr.flush()
+
+
+def parse_sweep(text):
+    """Every candidate the library's autotuner measured, from its log (reference format, src/autotune.cc:639-668):
+    [{"pdims": [r, c], "transport": name, "avg_ms": weighted average or None, "status": "measured"|"skipped"|"failed",
+    "model_ms": the xGMI-mesh estimate when printed}]."""
+    import re
+    out, cur = [], None
+    for line in text.splitlines():
+        m = re.match(r"CUDECOMP:\s+grid: (\d+) x (\d+), (?:halo )?backend: (.*?)\s*$", line)
+        if m:
+            cur = {"pdims": [int(m.group(1)), int(m.group(2))], "transport": m.group(3), "avg_ms": None, "status": "measured"}
+            out.append(cur)
+            continue
+        if cur is None:
+            continue
+        if "(failed, skipped)" in line:
+            cur["status"] = "failed"
+        elif "(skipped)" in line:
+            cur["status"] = "skipped"
+        m = re.match(r"CUDECOMP:\s+min/max/avg/std \[ms\]: ([\d.eE+-]+)/([\d.eE+-]+)/([\d.eE+-]+)/([\d.eE+-]+) \(weighted\)", line)
+        if m:
+            cur["avg_ms"] = round(float(m.group(3)), 4)
+        m = re.match(r"CUDECOMP:\s+xGMI-mesh model estimate \[ms\]: ([\d.eE+-]+)", line)
+        if m:
+            cur["model_ms"] = round(float(m.group(1)), 4)
+    return out
 
 
 def gpus_on_this_host():
@@ -461,10 +498,11 @@ def main():
             opt.transpose_use_inplace_buffers[i] = bool(args.inplace)
         if tune_backend:
             os.environ["CUDECOMP_AUTOTUNE_TRANSPOSE_BACKENDS"] = ",".join(lib_names[b] for b in sweep_backends)
-        with c_stdout_to_stderr():  # the sweep logs "CUDECOMP: ..." lines on stdout; keep ours a single JSON line
+        with c_stdout_to_stderr() as log:  # the sweep logs "CUDECOMP: ..." lines on stdout; keep ours a single JSON line
             gd = cd.cudecompGridDescCreate(h, cfg, opt)
         return gd, cfg, {"pdims": pin_pdims is None, "backend": tune_backend,
-                         "candidates": list(sweep_backends) if tune_backend else None}
+                         "candidates": list(sweep_backends) if tune_backend else None,
+                         "sweep": parse_sweep(log.text) if rank == 0 else None}
 
     def measure(pin_backend, pin_pdims, sweep_backends):
         """One complete measurement (out of place and in place) with one descriptor; returns the record pieces."""
@@ -617,6 +655,15 @@ def main():
         return out
 
     best, best_m, preflight = None, None, None
+    everything = []  # every (phase, grid, transport) this run measured, winner or not: the N > 1 line describes itself
+
+    def note(phase, m, cand):
+        if m.get("autotuned") and m["autotuned"].get("sweep"):
+            for c in m["autotuned"]["sweep"]:
+                everything.append(dict(c, phase=phase + " (library autotuner, %d+%d cycles)" % (2, 3)))
+        everything.append({"phase": phase + " (bench protocol)", "pdims": list(m["pdims"]), "transport": m["used"],
+                           "avg_ms": cand["ms_per_step"], "status": "measured" if m["ok"] else "round trip FAILED",
+                           "per_op_ms": cand["config"]["per_op_ms"], "direct_puts": m["counters"]["direct_puts"]})
     # ---- phase A: RCCL, process grid autotuned (or pinned) -- the transport the north star names; also the safety net
     if args.backend in ("auto", "nccl", "nccl_pl") or os.environ.get("BENCH_FORCE_RCCL_PHASE"):
         try:
@@ -625,6 +672,7 @@ def main():
             if all_ok(m["ok"]):
                 best = xgmi_block(record(m), m)
                 best_m = m
+                note("A: RCCL", m, best)
                 if rank == 0:
                     fallback_line[0] = json.loads(json.dumps(best))
                     sys.stderr.write("bench.py: RCCL phase: %dx%d grid, %.3f ms per cycle\n" % (m["pdims"][0], m["pdims"][1], best["ms_per_step"]))
@@ -680,13 +728,13 @@ def main():
                     m = measure(args.backend, args.pdims, None)
                 if all_ok(m["ok"]):
                     cand = xgmi_block(record(m, preflight=preflight), m)
+                    note("C: one-sided", m, cand)
                     if best is None or cand["ms_per_step"] < best["ms_per_step"]:
                         if best_m is not None:
                             release(best_m)
                         best, best_m = cand, m
                     else:
-                        best["config"]["also_measured"] = {"transport": m["used"], "pdims": list(m["pdims"]),
-                                                           "ms_per_step": cand["ms_per_step"], "preflight": preflight}
+                        best["config"]["preflight"] = preflight
                         release(m)
                 else:
                     if rank == 0:
@@ -707,6 +755,7 @@ def main():
     if rank == 0:
         if best is None:
             raise SystemExit("bench.py: no transport produced a valid result")
+        best["config"]["also_measured"] = everything
         emit(best)
     if best_m is not None:
         release(best_m)

@@ -418,7 +418,19 @@ cudecompResult_t cudecompFinalize(cudecompHandle_t handle) {
   try {
     checkHandle(handle);
     handle->initialized = false;
+    std::unique_ptr<Error> pending;
+    if (handle->peer) {
+      // same for exchanges whose descriptor is still alive (or leaked) when the library goes away
+      (void)hipDeviceSynchronize();
+      (void)hipGetLastError();
+      try {
+        peerCheckStatus(handle);
+      } catch (const Error& e) {
+        pending = std::make_unique<Error>(e);
+      }
+    }
     delete handle;
+    if (pending) throw *pending;
   }
   CD_API_CATCH()
   return CUDECOMP_RESULT_SUCCESS;
@@ -564,7 +576,10 @@ cudecompResult_t cudecompGridDescDestroy(cudecompHandle_t handle, cudecompGridDe
     checkGridDesc(handle, grid_desc);
     perfReport(handle, grid_desc);
     grid_desc->initialized = false;
-    delete grid_desc;
+    const bool one_sided = grid_desc->row.dev_epoch || grid_desc->col.dev_epoch;
+    delete grid_desc;  // (drains the device if the descriptor ran one-sided exchanges)
+    // the LAST exchange of a descriptor has no later call that would report a wait kernel that gave up: do it here
+    if (one_sided) peerCheckStatus(handle);
   }
   CD_API_CATCH()
   return CUDECOMP_RESULT_SUCCESS;

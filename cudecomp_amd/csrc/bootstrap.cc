@@ -407,6 +407,13 @@ std::unique_ptr<Bootstrap> makeTcpBootstrap(const LaunchEnv& env, int instance) 
       // listen on the interface the ranks were told to call (MASTER_ADDR), not on every interface of the host; only if
       // that address is not configured on this machine (NAT, a virtual IP) fall back to all interfaces
       sockaddr_in bind_addr = sa;
+      // A HOST NAME that resolves to a loopback alias on rank 0's own machine (Debian's 127.0.1.1 entry) says nothing
+      // about where the other nodes will call: listen everywhere then (the job-secret greeting still guards the hub).
+      // A literal loopback address means a single-node job and stays on loopback.
+      const bool loopback = (ntohl(sa.sin_addr.s_addr) >> 24) == 127;
+      in_addr literal{};
+      if (loopback && ::inet_pton(AF_INET, env.addr.c_str(), &literal) != 1 && env.addr != "localhost")
+        bind_addr.sin_addr.s_addr = htonl(INADDR_ANY);
       int brc = ::bind(lfd, reinterpret_cast<sockaddr*>(&bind_addr), sizeof(bind_addr));
       if (brc != 0 && errno == EADDRNOTAVAIL) {
         bind_addr.sin_addr.s_addr = htonl(INADDR_ANY);

@@ -91,6 +91,9 @@ struct cudecompHandle {
   std::vector<uint64_t> slot_high;  // highest counter value this rank has used in each row
   int acquireSlot();
   void releaseSlot(int slot, uint64_t high);
+  // bumped whenever a library region is mapped or unmapped (cudecompMalloc / cudecompFree): captured whole-operation
+  // graphs hold the peers' IPC addresses of such regions and must not outlive them
+  uint64_t region_generation = 0;
 
   ~cudecompHandle();
 };
@@ -124,6 +127,7 @@ struct cudecompGridDesc {
   // runAsGraph); op_graph_seen: (plan, buffers) that ran eagerly once and are captured on their next call
   std::map<PackGraphKey, hipGraphExec_t> op_graphs;
   std::set<PackGraphKey> op_graph_seen;
+  uint64_t op_graph_generation = 0;  // handle->region_generation the graphs above were captured under
   hipStream_t graph_stream = nullptr;
   int64_t graph_launches = 0;
   int64_t direct_puts = 0;  // NVSHMEM_SM transposes that wrote straight into the peers' output pencils

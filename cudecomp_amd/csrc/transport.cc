@@ -187,6 +187,7 @@ class PeerContext {
       CD_PEER_ERROR(error.empty() ? std::string("IPC mapping failed on another rank") : error);
     }
     region_by_id_[r.id] = r.base;
+    h_->region_generation++;
     auto ins = regions_.emplace(r.base, std::move(r));
     return &ins.first->second;
   }
@@ -218,6 +219,7 @@ class PeerContext {
     closePeers(it->second);
     region_by_id_.erase(it->second.id);
     regions_.erase(it);
+    h_->region_generation++;
     h_->boot->barrier();
   }
 
@@ -284,8 +286,10 @@ class PeerContext {
     if (!usable(ci)) CD_PEER_ERROR("the one-sided transport needs all members of the communicator on one node");
     const uint64_t seq = ++ci.mail_seq;
     Mail& mine = mail(ci.barrier_slot, h_->rank, (int)(seq & 1));
+    // every descriptor of the mailbox is (re)written on every call: a member that posts fewer buffers than a peer asks
+    // for must never show that peer what it posted two calls ago
     mine.nbuf = (uint64_t)nbuf;
-    for (int b = 0; b < nbuf; ++b) mine.buf[b] = describe(ptrs[b], flags ? flags[b] : 0);
+    for (int b = 0; b < kMailBufs; ++b) mine.buf[b] = (b < nbuf) ? describe(ptrs[b], flags ? flags[b] : 0) : describe(nullptr, 0);
     mine.seq.store(seq, std::memory_order_release);
     Resolved out;
     for (int b = 0; b < nbuf; ++b) {
@@ -297,8 +301,11 @@ class PeerContext {
       const int g = ci.global_ranks[m];
       Mail& theirs = mail(ci.barrier_slot, g, (int)(seq & 1));
       spinUntil(theirs.seq, seq, "the per-call rendezvous of a one-sided exchange");
+      const int their_nbuf = (int)std::min<uint64_t>(theirs.nbuf, (uint64_t)kMailBufs);
       for (int b = 0; b < nbuf; ++b) {
-        const BufDesc d = theirs.buf[b];
+        // a buffer the member did not post counts as "not offered" (flags 0, not mappable): the members of a call may
+        // disagree about optional buffers (the direct put's output pencil), never about what that means
+        const BufDesc d = (b < their_nbuf) ? theirs.buf[b] : BufDesc{};
         out.flags[b][m] = d.flags;
         out.mappable[b][m] = d.mappable;
         if (g == h_->rank) out.remote[b][m] = static_cast<char*>(const_cast<void*>(ptrs[b]));

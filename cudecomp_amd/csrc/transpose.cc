@@ -106,6 +106,18 @@ bool runAsGraph(cudecompHandle_t h, cudecompGridDesc_t gd, const TransposePlan& 
     (void)hipGetLastError();
     return false;  // the caller is capturing already: our launches simply join its graph
   }
+  // The captured nodes hold the peers' IPC addresses of the workspace: any cudecompMalloc / cudecompFree since the
+  // capture may have changed what those addresses mean (a workspace freed and re-created at the same local address is
+  // mapped elsewhere by the peers), so the graphs of this descriptor are dropped and captured again.
+  if (gd->op_graph_generation != h->region_generation) {
+    for (auto& kv : gd->op_graphs) (void)hipGraphExecDestroy(kv.second);
+    gd->op_graphs.clear();
+    gd->op_graph_seen.clear();
+    gd->op_graph_generation = h->region_generation;
+  }
+  // replays skip peerBegin, and inside a capture its error would read as "capture failed": report a wait kernel of an
+  // earlier call that gave up here, as the error it is
+  peerCheckStatus(h);
   const cudecompGridDesc::PackGraphKey gkey{key, bufs[0], bufs[1], bufs[2], es};
   auto it = gd->op_graphs.find(gkey);
   bool captured_now = false;

@@ -36,6 +36,39 @@ def index_queries(rank, nranks, args):
     return out
 
 
+def two_handles(rank, nranks, args):
+    """Reference tests/ctest/api_tests.cc:575-656 on every rank of a distributed job: two LIVE handles over the same
+    communicator with independent descriptors (row-major on the first, column-major on the second), each descriptor
+    only valid with its own handle, both finalised in creation order."""
+    L = cd.lib()
+    h1 = cd.cudecompInit()
+    h2 = cd.cudecompInit()
+    assert h1.value != h2.value
+    pd = tuple(args["pdims"])
+    gd1 = cd.cudecompGridDescCreate(h1, cd.make_config(args["gdims"], pd, rank_order=cd.RANK_ORDER_ROW_MAJOR))
+    gd2 = cd.cudecompGridDescCreate(h2, cd.make_config(args["gdims"], pd, rank_order=cd.RANK_ORDER_COL_MAJOR))
+    out = {"rank": rank, "cross": [], "pencil_row_major": [], "pencil_col_major": []}
+    out["cross"].append(L.cudecompGetGridDescConfigVersioned(h2, gd1, C.byref(cd.GridDescConfig()), 104, 1))
+    out["cross"].append(L.cudecompGridDescDestroy(h2, gd1))
+    unused = C.c_void_p()
+    out["cross"].append(L.cudecompMalloc(h2, gd1, C.byref(unused), 1024))
+    out["unused_is_null"] = not unused.value
+    for axis in range(3):
+        out["pencil_row_major"].append(cd.cudecompGetPencilInfo(h1, gd1, axis, args.get("halo"), args.get("padding")).as_dict())
+        out["pencil_col_major"].append(cd.cudecompGetPencilInfo(h2, gd2, axis, args.get("halo"), args.get("padding")).as_dict())
+    out["rank_orders"] = [cd.cudecompGetGridDescConfig(h1, gd1).rank_order, cd.cudecompGetGridDescConfig(h2, gd2).rank_order]
+    if args.get("destroy_descriptors", True):
+        cd.cudecompGridDescDestroy(h1, gd1)
+        cd.cudecompGridDescDestroy(h2, gd2)
+    cd.cudecompFinalize(h1)  # creation order (FinalizesMultipleHandlesInCreationOrder)
+    # the second handle must be fully usable after the first is gone
+    gd3 = cd.cudecompGridDescCreate(h2, cd.make_config(args["gdims"], pd))
+    out["after_first_finalize"] = cd.cudecompGetPencilInfo(h2, gd3, 0, args.get("halo"), args.get("padding")).as_dict()
+    cd.cudecompGridDescDestroy(h2, gd3)
+    cd.cudecompFinalize(h2)
+    return out
+
+
 # ---- numpy execution of the PRODUCT's plans (host-logic check, no GPU) -------------------------------
 def _view(buf, off, extent, strides):
     es = buf.itemsize

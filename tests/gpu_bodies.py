@@ -598,3 +598,74 @@ def malloc_timing(rank, nranks, args):
         out[str(nbytes)] = [round((t1 - t0) / len(ptrs) * 1e3, 3), round((t2 - t1) / len(ptrs) * 1e3, 3)]
     cd.cudecompGridDescDestroy(h, gd)
     return out
+
+
+def two_handles_alternating(rank, nranks, args):
+    """Two LIVE handles in one job (reference tests/ctest/api_tests.cc:575-656), each with its own descriptor (different
+    rank order and backend), workspace and transport state, transposing ALTERNATELY hop by hop on the same stream; every
+    cell of every output pencil is compared on the device with its closed form.  The first handle is finalised while
+    the second keeps working."""
+    h1, h2 = cd.cudecompInit(), cd.cudecompInit()
+    gdims, pd, kind = args["gdims"], args["pdims"], args.get("kind", 1)
+    es = orc.KINDS[kind][1]
+    idt = torch.int32 if es == 4 else torch.int64
+    words = 2 if es == 16 else 1
+    torch.zeros(1, device="cuda")
+    sides = []
+    for h, order, backend in ((h1, cd.RANK_ORDER_ROW_MAJOR, args["backends"][0]), (h2, cd.RANK_ORDER_COL_MAJOR, args["backends"][1])):
+        gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims, pd, rank_order=order, axis_contiguous=args.get("ac", (0, 0, 0)),
+                                                         transpose_backend=backend))
+        pin = [cd.cudecompGetPencilInfo(h, gd, ax) for ax in range(3)]
+        nel = max(p.size for p in pin)
+        work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * es)
+        a = torch.zeros(nel * words, dtype=idt, device="cuda")
+        b = torch.full((nel * words,), -3, dtype=idt, device="cuda")
+        a[:pin[0].size * words] = expected_pencil_words(pin[0], gdims, es)
+        sides.append({"h": h, "gd": gd, "pin": pin, "work": work, "cur": a, "nxt": b})
+    failures = []
+    for it in range(args.get("cycles", 2)):
+        for op in cd.OPS:
+            ao = orc.OP_AXES[op][1]
+            for s in sides:  # both issued before anything is synchronised: the two handles' exchanges interleave
+                cd.cudecompTranspose(op, s["h"], s["gd"], s["cur"].data_ptr(), s["nxt"].data_ptr(), s["work"],
+                                     cd.DTYPE_OF_KIND[kind], stream=G.stream_ptr())
+            torch.cuda.synchronize()
+            for k, s in enumerate(sides):
+                exp = expected_pencil_words(s["pin"][ao], gdims, es)
+                got = s["nxt"][:s["pin"][ao].size * words]
+                if not torch.equal(got, exp):
+                    failures.append("rank %d handle %d cycle %d %s: %d cells differ" % (rank, k, it, op, int((got != exp).sum())))
+                    got.copy_(exp)
+                s["cur"].fill_(-5)
+                s["cur"], s["nxt"] = s["nxt"], s["cur"]
+    # first handle goes away (creation order), the second runs one more cycle on its own
+    s = sides[0]
+    cd.cudecompFree(s["h"], s["gd"], s["work"])
+    cd.cudecompGridDescDestroy(s["h"], s["gd"])
+    cd.cudecompFinalize(s["h"])
+    s = sides[1]
+    for op in cd.OPS:
+        ao = orc.OP_AXES[op][1]
+        cd.cudecompTranspose(op, s["h"], s["gd"], s["cur"].data_ptr(), s["nxt"].data_ptr(), s["work"], cd.DTYPE_OF_KIND[kind],
+                             stream=G.stream_ptr())
+        torch.cuda.synchronize()
+        exp = expected_pencil_words(s["pin"][ao], gdims, es)
+        if not torch.equal(s["nxt"][:s["pin"][ao].size * words], exp):
+            failures.append("rank %d second handle alone %s: cells differ" % (rank, op))
+        s["cur"], s["nxt"] = s["nxt"], s["cur"]
+    cd.cudecompFree(s["h"], s["gd"], s["work"])
+    cd.cudecompGridDescDestroy(s["h"], s["gd"])
+    cd.cudecompFinalize(s["h"])
+    return {"failures": failures}
+
+
+def link_info(rank, nranks, args):
+    """What the start-up link probe of the one-sided transport measured (it runs when the transport comes up, i.e. with
+    the first descriptor that selects a one-sided backend)."""
+    h = _handle(rank)
+    gd = cd.cudecompGridDescCreate(h, cd.make_config((64, 64, 64), (1, nranks), transpose_backend=cd.TRANSPOSE_COMM_NVSHMEM))
+    work = cd.cudecompMalloc(h, gd, 1 << 20)
+    info = cd.cudecompExtGetLinkInfo(h)
+    cd.cudecompFree(h, gd, work)
+    cd.cudecompGridDescDestroy(h, gd)
+    return info

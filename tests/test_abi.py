@@ -253,3 +253,36 @@ def test_empty_pencils_and_wide_halos_are_rejected_by_the_planner(handle):
     # single rank, in place, identical layout: nothing to do, returns before touching the device
     assert L.cudecompTransposeXToY(handle, gd, 8, 8, 8, cd.FLOAT, None, None, None, None, None) == cd.RESULT_SUCCESS
     cd.cudecompGridDescDestroy(handle, gd)
+
+
+def test_multiple_live_handles_single_process():
+    """api_tests.cc:575-656 (SupportsMultipleLiveHandlesWithIndependentResources,
+    FinalizesMultipleHandlesInCreationOrder) in one process."""
+    from tests import bodies
+    out = bodies.two_handles(0, 1, {"gdims": (9, 10, 11), "pdims": (1, 1)})
+    assert out["cross"] == [cd.RESULT_INVALID_USAGE] * 3 and out["unused_is_null"]
+    assert out["rank_orders"] == [cd.RANK_ORDER_ROW_MAJOR, cd.RANK_ORDER_COL_MAJOR]
+    assert out["pencil_row_major"] == out["pencil_col_major"]  # one rank: the order does not matter
+
+
+def test_multiple_live_handles_four_ranks(golden_dir):
+    """The same on a 2 x 2 job: each handle's descriptor yields ITS rank order's pencils (the reference's golden
+    vectors for 9 x 10 x 11, tests/ctest/api_tests.cc:92-153, row- and column-major), descriptors are rejected by the
+    other handle on every rank, finalisation in creation order leaves the second handle usable."""
+    from tests.mp import run_ranks
+    gold = json.load(open(os.path.join(golden_dir, "pencil_info.json")))
+    args = {"gdims": gold["gdims"], "pdims": gold["pdims"], "halo": gold["halo_extents"], "padding": gold["padding"]}
+    res = run_ranks(4, "tests.bodies", "two_handles", args)
+    by_rank = {r["rank"]: r for r in res}
+    for r in res:
+        assert r["cross"] == [cd.RESULT_INVALID_USAGE] * 3 and r["unused_is_null"]
+        assert r["rank_orders"] == [cd.RANK_ORDER_ROW_MAJOR, cd.RANK_ORDER_COL_MAJOR]
+        assert r["after_first_finalize"] == r["pencil_row_major"][0]
+    for variant in ("row_major", "col_major"):
+        assert len(gold[variant]) == 12
+        for g in gold[variant]:
+            mine = by_rank[g["rank"]]["pencil_" + variant][g["axis"]]
+            assert mine == {k: v for k, v in g.items() if k not in ("axis", "rank")}, (variant, g["axis"], g["rank"])
+    # and the two rank orders really differ on the off-diagonal ranks
+    assert by_rank[1]["pencil_row_major"] != by_rank[1]["pencil_col_major"]
+    assert by_rank[1]["pencil_col_major"] == by_rank[2]["pencil_row_major"]

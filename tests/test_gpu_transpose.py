@@ -129,6 +129,26 @@ def test_round_trip_and_checksum_at_benchmark_size():
     cd.cudecompGridDescDestroy(h, gd)
 
 
+@pytest.mark.parametrize("inplace", [False, True], ids=["out_of_place", "in_place"])
+@pytest.mark.parametrize("ac", [(1, 1, 1), (0, 0, 0)], ids=["axis_contiguous", "default_layout"])
+def test_bench_workload_every_cell(ac, inplace):
+    """bench.py's N=1 workload itself -- 1x1 grid, 1024^3 fp64, both layouts, in and out of place -- with EVERY cell of
+    every hop compared on the device against the closed form of that pencil (reference:
+    tests/ctest/transpose_tests.cc:356-378 compares every interior cell; nothing is sampled here either)."""
+    args = {"gdims": (1024, 1024, 1024), "pdims": (1, 1), "kind": 1, "ac": ac, "inplace": inplace}
+    for r in run_ranks(1, "tests.gpu_bodies", "cycle_exact", args, timeout=600):
+        assert r["failures"] == []
+
+
+def test_more_than_2_31_elements_per_pencil_every_cell():
+    """Maximum-size edge, every cell: 2048 x 1024 x 1056 fp32 = 2.2e9 elements (> 2^31) in one pencil, each hop compared
+    on the device with the closed form (low 31 bits of the global linear index, which itself exceeds 2^31)."""
+    for ac in ((1, 1, 1), (0, 0, 0)):
+        args = {"gdims": (2048, 1024, 1056), "pdims": (1, 1), "kind": 0, "ac": ac}
+        for r in run_ranks(1, "tests.gpu_bodies", "cycle_exact", args, timeout=900):
+            assert r["failures"] == []
+
+
 def test_more_than_2_31_elements_per_pencil():
     """Maximum-size edge: 2048 x 1024 x 1056 fp32 = 2.2e9 elements (> 2^31) in one pencil; 64-bit indexing in
     every kernel flavour.  Properties only: the cycle returns the input bit for bit and each hop preserves the
@@ -175,3 +195,14 @@ def test_one_sided_exchanges_tolerate_rank_skew(backend):
                 "iterations": 3, "skew_ms": 8}
         for r in run_ranks(4, "tests.gpu_bodies", "repeated_cycle", args, timeout=300):
             assert r["failures"] == []
+
+
+@pytest.mark.parametrize("backends", [(cd.TRANSPOSE_COMM_NVSHMEM, cd.TRANSPOSE_COMM_MPI_P2P),
+                                      (cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_NVSHMEM_SM)],
+                         ids=["nvshmem+mpi_p2p", "nvshmem_pl+nvshmem_sm"])
+def test_two_live_handles_transpose_alternately(backends):
+    """api_tests.cc:575-656 with work: two handles, independent descriptors / workspaces / transports, exchanges of both
+    in flight together, first handle finalised while the second continues (4 ranks, every cell)."""
+    args = {"gdims": (64, 48, 80), "pdims": (2, 2), "kind": 1, "ac": K.ALL_AC, "backends": list(backends)}
+    for r in run_ranks(4, "tests.gpu_bodies", "two_handles_alternating", args, timeout=300):
+        assert r["failures"] == []
