@@ -223,7 +223,22 @@ def cpu_baseline_mpi(sample, size, layout):
         if not rec["round_trip_ok"]:
             return None
         frac = "the benchmark's own size" if sample == size else "1/%d of the benchmark's volume" % (size // sample) ** 3
+        # BASELINE config 1 at its own shape: 256^3 fp32 slab decomposition on 2 host-MPI ranks, 3 + 5 cycles (< 1 s)
+        config1 = {}
+        for grid in ((2, 1), (1, 2)):
+            try:
+                o1 = subprocess.run([mpirun, "-np", "2", exe, "256", str(grid[0]), str(grid[1]), "0", "3", "5", "0"], env=env,
+                                    capture_output=True, text=True, timeout=120)
+                r1 = json.loads([l for l in o1.stdout.splitlines() if l.startswith("{")][-1])
+                config1["%dx%d" % grid] = {"GBps": round(r1["gbps"], 3), "cycle_ms": {
+                    "avg": round(r1["cycle_s"] * 1e3, 3), "min": round(r1["cycle_s_min"] * 1e3, 3),
+                    "max": round(r1["cycle_s_max"] * 1e3, 3), "std": round(r1["cycle_s_std"] * 1e3, 3)},
+                    "round_trip_ok": r1["round_trip_ok"]}
+            except Exception as e1:
+                config1["%dx%d" % grid] = "unavailable: %s" % str(e1)[:80]
         return {"value": round(rec["gbps"], 4), "unit": "GB/s", "cores": ranks, "kind": "port",
+                "config1_256cube_fp32_2_ranks": dict(config1, what="BASELINE.json configs[0]: 256^3 fp32 slab, 2-rank host-MPI "
+                                                     "a2a CPU path (oracle pack/unpack + MPI_Alltoallv), 3 warm-up + 5 timed cycles"),
                 "sample": "%d^3 fp64 X->Y->Z->Y->X cycle on host memory (%s), %d MPI ranks (%dx%d grid, one per core; MPICH "
                           "shared-memory MPI_Alltoallv), %s layout, out-of-place, %.3f s per cycle, %d warm-up + %d timed "
                           "cycles, %.1f s in total" % (sample, frac, ranks, pr, pc, layout, rec["cycle_s"], warm, timed, dt)}

@@ -95,7 +95,8 @@ class ExtHaloPlan(C.Structure):
 
 class ExtCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("graphs_captured", "graph_launches", "local", "rccl", "mpi", "peer_barrier",
-                                          "peer_fused", "peer_pipelined", "direct_puts")]
+                                          "peer_fused", "peer_pipelined", "direct_puts", "workspace_pool_hits",
+                                          "stale_ipc_mappings")]
 
 
 class ExtLinkInfo(C.Structure):

@@ -379,6 +379,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->self_exchange = envIsOne("CUDECOMP_TEST_SELF_EXCHANGE");
     if (const char* v = std::getenv("CUDECOMP_RCCL_NATIVE_ALLTOALL")) h->rccl_native_alltoall = std::strtol(v, nullptr, 10) != 0;
     h->direct_put = !envIsOne("CUDECOMP_DISABLE_DIRECT_PUT");
+    h->debug_verify_exchange = envIsOne("CUDECOMP_DEBUG_VERIFY_EXCHANGE");
     if (const char* v = std::getenv("CUDECOMP_PEER_TIMEOUT")) {
       const double t = std::strtod(v, nullptr);
       if (t > 0) h->peer_timeout_s = t;

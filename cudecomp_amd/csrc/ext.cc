@@ -298,6 +298,7 @@ cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDes
     out->peer_fused = gd->path_count[PATH_PEER_FUSED];
     out->peer_pipelined = gd->path_count[PATH_PEER_PIPELINED];
     out->direct_puts = gd->direct_puts;
+    peerPoolCounters(handle, &out->workspace_pool_hits, &out->stale_ipc_mappings);
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {

@@ -76,6 +76,7 @@ struct cudecompHandle {
   bool self_exchange = false;         // CUDECOMP_TEST_SELF_EXCHANGE=1: one-member communicators exchange with themselves
                                       // through the selected transport (drives real RCCL / the peer transport on one GPU)
   bool rccl_native_alltoall = true;   // CUDECOMP_RCCL_NATIVE_ALLTOALL=0: grouped send/recv even where ncclAllToAll applies
+  bool debug_verify_exchange = false;  // CUDECOMP_DEBUG_VERIFY_EXCHANGE=1: checksum what one-sided exchanges delivered (host-synchronous)
   bool direct_put = true;             // CUDECOMP_DISABLE_DIRECT_PUT=1: NVSHMEM_SM always lands in the receive area + unpack
   double peer_timeout_s = 120.0;      // CUDECOMP_PEER_TIMEOUT: how long a rank waits for a peer (host rendezvous, device flags)
   int peer_copy_engine = 0;           // 0 = copy engines (hipMemcpyAsync), 1 = compute-unit copy kernel; CUDECOMP_PEER_COPY_ENGINE

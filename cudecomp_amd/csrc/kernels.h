@@ -56,4 +56,10 @@ void launchSignal(const unsigned long long* epoch, const FlagList& flags, hipStr
 void launchWait(const unsigned long long* epoch, const FlagList& flags, unsigned long long* status, double timeout_s,
                 hipStream_t stream);
 
+// stamp / verify the first word of every 4-KiB page of a shared buffer (see sync.hip)
+void launchTagPages(void* base, size_t bytes, unsigned long long seed, hipStream_t stream);
+void launchCheckPages(const void* base, size_t bytes, unsigned long long seed, unsigned long long* bad, hipStream_t stream);
+// debug aid: out2[0] += sum of the 32-bit words of [p, p + bytes), out2[1] += position-weighted sum (mod 2^64)
+void launchChecksum(const void* p, size_t bytes, unsigned long long* out2, hipStream_t stream);
+
 }  // namespace cudecomp

@@ -14,6 +14,8 @@
 //                   `timeout_ticks` of the 100 MHz wall clock and reports through `status` (host-visible).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "errors.h"
 #include "kernels.h"
 
@@ -52,7 +54,71 @@ __global__ void wait_k(const u64* epoch, const FlagList flags, u64* status, long
   }
 }
 
+// position-weighted checksum of a byte range taken as 32-bit words: out[0] += sum(w_i), out[1] += sum(w_i * (i + 1))
+// (mod 2^64) -- a moved, missing or stale block changes it.  Debug aid of the one-sided exchanges
+// (CUDECOMP_DEBUG_VERIFY_EXCHANGE), not part of any data path.
+__global__ void checksum_k(const unsigned int* p, unsigned long long words, u64* out) {
+  u64 s1 = 0, s2 = 0;
+  for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < words; i += (u64)gridDim.x * blockDim.x) {
+    const u64 w = __builtin_nontemporal_load(p + i);
+    s1 += w;
+    s2 += w * (i + 1);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off);
+    s2 += __shfl_down(s2, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, s1);
+    atomicAdd(out + 1, s2);
+  }
+}
+
+// Page tags of a freshly shared buffer (transport.cc: registerRegion): the owner stamps the first word of every 4-KiB
+// page with a value derived from a per-registration seed, every importer reads the stamps back THROUGH ITS NEW MAPPING.
+// A mapping that does not lead to the owner's pages (stale IPC mappings of re-created allocations) shows
+// as mismatching pages.
+__device__ __forceinline__ u64 pageTag(u64 seed, u64 page) {
+  u64 x = seed + page * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 29;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 32;
+  return x;
+}
+__global__ void tag_pages_k(u64* base, u64 pages, u64 seed) {
+  for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < pages; i += (u64)gridDim.x * blockDim.x)
+    __hip_atomic_store(base + i * 512, pageTag(seed, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void check_pages_k(const u64* base, u64 pages, u64 seed, u64* bad) {
+  u64 mine = 0;
+  for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < pages; i += (u64)gridDim.x * blockDim.x)
+    if (__hip_atomic_load(base + i * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != pageTag(seed, i)) ++mine;
+  if (mine) atomicAdd(bad, mine);
+}
+
 }  // namespace
+
+void launchTagPages(void* base, size_t bytes, unsigned long long seed, hipStream_t stream) {
+  const unsigned long long pages = bytes / 4096;
+  if (pages == 0) return;
+  tag_pages_k<<<(unsigned int)std::min<unsigned long long>((pages + 255) / 256, 1024), 256, 0, stream>>>(static_cast<u64*>(base), pages, seed);
+  CD_CHECK_HIP(hipGetLastError());
+}
+
+void launchCheckPages(const void* base, size_t bytes, unsigned long long seed, unsigned long long* bad, hipStream_t stream) {
+  const unsigned long long pages = bytes / 4096;
+  if (pages == 0) return;
+  check_pages_k<<<(unsigned int)std::min<unsigned long long>((pages + 255) / 256, 1024), 256, 0, stream>>>(static_cast<const u64*>(base), pages, seed, bad);
+  CD_CHECK_HIP(hipGetLastError());
+}
+
+void launchChecksum(const void* p, size_t bytes, unsigned long long* out2, hipStream_t stream) {
+  if (bytes < 4) return;
+  const unsigned long long words = bytes / 4;
+  const unsigned int blocks = (unsigned int)std::min<unsigned long long>((words + 1023) / 1024, 2048);
+  checksum_k<<<blocks, 256, 0, stream>>>(static_cast<const unsigned int*>(p), words, out2);
+  CD_CHECK_HIP(hipGetLastError());
+}
 
 void launchEpochBegin(unsigned long long* epoch, unsigned long long* ready, hipStream_t stream) {
   epoch_begin_k<<<1, 64, 0, stream>>>(epoch, ready);

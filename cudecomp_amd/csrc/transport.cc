@@ -105,6 +105,14 @@ class PeerContext {
   // collective over the handle's communicator
   explicit PeerContext(cudecompHandle_t h) : h_(h) {
     debug_ = std::getenv("CUDECOMP_DEBUG_PEER") != nullptr;
+    // CUDECOMP_WORKSPACE_POOL_MIB: how much released workspace memory stays parked (0 = none: every cudecompFree really
+    // frees); default 1/8 of the device's memory, at most 32 GiB.  CUDECOMP_VERIFY_IPC_MAPPINGS=0 skips the page tags.
+    pool_limit_ = (size_t)32 << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) pool_limit_ = std::min(pool_limit_, total_b / 8);
+    else (void)hipGetLastError();
+    if (const char* v = std::getenv("CUDECOMP_WORKSPACE_POOL_MIB")) pool_limit_ = (size_t)std::strtoull(v, nullptr, 10) << 20;
+    if (const char* v = std::getenv("CUDECOMP_VERIFY_IPC_MAPPINGS")) verify_mappings_ = std::strtol(v, nullptr, 10) != 0;
     openBoard();
   }
 
@@ -112,8 +120,10 @@ class PeerContext {
     if (board_registered_) (void)hipHostUnregister(board_);
     if (board_) ::munmap(board_, board_bytes_);
     for (auto& kv : regions_) closePeers(kv.second);
+    for (auto& pk : pool_) (void)hipFree(pk.base);  // parked workspaces: released with the library
     for (auto& kv : imports_)
       if (kv.second.mapped) (void)hipIpcCloseMemHandle(kv.second.mapped);
+    if (verify_count_) (void)hipFree(verify_count_);
     for (hipStream_t s : copy_streams_) (void)hipStreamDestroy(s);
     for (hipEvent_t e : copy_events_) (void)hipEventDestroy(e);
     (void)hipGetLastError();
@@ -136,13 +146,17 @@ class PeerContext {
   }
 
   // collective over the handle's communicator
-  Region* registerRegion(void* base, size_t bytes) {
+  // `stale` (optional): set when some member's NEW mapping of a peer's buffer does not lead to that buffer (page tags do
+  // not read back); the region is then not registered and nullptr is returned -- agreed by all ranks.
+  Region* registerRegion(void* base, size_t bytes, bool* stale = nullptr) {
     struct Wire {
       hipIpcMemHandle_t handle;
       unsigned long long bytes;
+      unsigned long long seed;  // of the page tags the owner stamped into the buffer
       int pid;
     };
     enablePeerAccessOnce();
+    if (stale) *stale = false;
     // Failures are agreed on collectively (a rank that threw on its own would leave the others waiting in the
     // next collective): everybody tries, then everybody learns whether anybody failed.
     Wire mine{};
@@ -154,6 +168,18 @@ class PeerContext {
     }
     mine.bytes = error.empty() ? bytes : 0;  // 0 = "I have nothing to offer"
     mine.pid = (int)::getpid();
+    // Stamp every page before anybody maps it: an importer that ends up with a mapping of something else (the platform
+    // can hand back the mapping of a PREDECESSOR of this allocation) must not go unnoticed.
+    mine.seed = ((unsigned long long)mine.pid << 32) ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^
+                ((unsigned long long)next_region_id_ << 20);
+    if (verify_mappings_ && error.empty()) {
+      launchTagPages(base, bytes, mine.seed, nullptr);
+      if (hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        error = "stamping the page tags of a new workspace failed";
+        mine.bytes = 0;
+      }
+    }
     std::vector<Wire> all(h_->nranks);
     h_->boot->allgather(&mine, all.data(), sizeof(Wire));
     Region r;
@@ -181,10 +207,40 @@ class PeerContext {
       }
       r.peer_base[p] = static_cast<char*>(mapped);
     }
+    // read every peer's page tags back through the mapping just made
+    bool my_stale = false;
+    if (verify_mappings_ && error.empty()) {
+      if (!verify_count_) (void)hipMalloc(reinterpret_cast<void**>(&verify_count_), sizeof(unsigned long long));
+      for (int p = 0; p < h_->nranks && verify_count_; ++p) {
+        if (p == h_->rank || !r.peer_base[p]) continue;
+        unsigned long long bad = 0;
+        if (hipMemcpy(verify_count_, &bad, sizeof(bad), hipMemcpyHostToDevice) != hipSuccess) break;
+        launchCheckPages(r.peer_base[p], (size_t)all[p].bytes, all[p].seed, verify_count_, nullptr);
+        if (hipMemcpy(&bad, verify_count_, sizeof(bad), hipMemcpyDeviceToHost) != hipSuccess) {
+          (void)hipGetLastError();
+          bad = 1;
+        }
+        if (bad) {
+          my_stale = true;
+          stale_mappings_seen_++;
+          if (debug_ || std::getenv("CUDECOMP_VERBOSE"))
+            fprintf(stderr, "CUDECOMP:WARN rank %d: the new IPC mapping of rank %d's workspace (%llu bytes) does not show its "
+                            "page tags on %llu of %llu pages: stale mapping, the workspace will be re-created\n", h_->rank, p,
+                    all[p].bytes, bad, all[p].bytes / 4096);
+        }
+      }
+    }
     const bool anyone_failed = h_->boot->allreduceOr(!error.empty());  // also: everybody has finished mapping
     if (anyone_failed) {
       closePeers(r);
       CD_PEER_ERROR(error.empty() ? std::string("IPC mapping failed on another rank") : error);
+    }
+    if (verify_mappings_ && h_->boot->allreduceOr(my_stale)) {
+      closePeers(r);
+      h_->boot->barrier();  // everybody has let go of everybody's buffer: the owners may dispose of them
+      if (stale) *stale = true;
+      if (!stale) CD_PEER_ERROR("a new IPC mapping of a peer's workspace does not lead to that workspace (stale mapping)");
+      return nullptr;
     }
     region_by_id_[r.id] = r.base;
     h_->region_generation++;
@@ -222,6 +278,55 @@ class PeerContext {
     h_->region_generation++;
     h_->boot->barrier();
   }
+
+  // ---- pool of released regions ---------------------------------------------------------------------------------
+  // cudecompFree parks a library region -- allocation AND the peers' mappings stay -- and cudecompMalloc hands it out
+  // again for requests it fits.  Two reasons: mapping a buffer into every rank of the node is the expensive part of
+  // cudecompMalloc, and re-creating allocations is what exposes the platform's stale-IPC-mapping behaviour (DESIGN.md
+  // section 9).  Every rank sees the same sequence of (collective) malloc / free calls with the same (max-reduced)
+  // sizes, so the pools are identical everywhere and so is every decision taken from them.
+  void* takeFromPool(size_t bytes) {
+    int best = -1;
+    for (int i = 0; i < (int)pool_.size(); ++i) {
+      if (pool_[i].bytes < bytes || pool_[i].bytes > std::max(2 * bytes, bytes + ((size_t)64 << 20))) continue;
+      if (best < 0 || pool_[i].bytes < pool_[best].bytes) best = i;
+    }
+    if (best < 0) return nullptr;
+    void* p = pool_[best].base;
+    pool_bytes_ -= pool_[best].bytes;
+    pool_.erase(pool_.begin() + best);
+    pool_hits_++;
+    return p;
+  }
+  // returns the regions that must really be released now (oldest first) to stay under the pool's limit
+  std::vector<void*> park(void* base) {
+    std::vector<void*> evict;
+    Region* r = find(base);
+    if (!r || r->base != base) return evict;
+    pool_.push_back(Parked{r->base, r->bytes});
+    pool_bytes_ += r->bytes;
+    while (pool_.size() > 1 && (pool_bytes_ > pool_limit_ || (int)pool_.size() > kMaxParked)) {
+      evict.push_back(pool_.front().base);
+      pool_bytes_ -= pool_.front().bytes;
+      pool_.erase(pool_.begin());
+    }
+    if (pool_.size() == 1 && pool_bytes_ > pool_limit_) {  // larger than the whole pool: not kept at all
+      evict.push_back(pool_.front().base);
+      pool_bytes_ = 0;
+      pool_.clear();
+    }
+    return evict;
+  }
+  bool poolEnabled() const { return pool_limit_ > 0; }
+  std::vector<void*> drainPool() {
+    std::vector<void*> all;
+    for (auto& p : pool_) all.push_back(p.base);
+    pool_.clear();
+    pool_bytes_ = 0;
+    return all;
+  }
+  int64_t poolHits() const { return pool_hits_; }
+  int64_t staleMappingsSeen() const { return stale_mappings_seen_; }
 
   // ---- host barrier among the members of a row / column communicator (set-up paths, probes) ---------------
   void barrier(cudecompCommInfo& ci) {
@@ -534,6 +639,16 @@ class PeerContext {
   std::map<std::pair<int, uint64_t>, Import> imports_;
   std::vector<hipStream_t> copy_streams_;
   std::vector<hipEvent_t> copy_events_;
+  struct Parked {
+    char* base;
+    size_t bytes;
+  };
+  static constexpr int kMaxParked = 32;
+  std::vector<Parked> pool_;
+  size_t pool_bytes_ = 0, pool_limit_ = 0;
+  int64_t pool_hits_ = 0, stale_mappings_seen_ = 0;
+  bool verify_mappings_ = true;
+  unsigned long long* verify_count_ = nullptr;
   bool peer_access_done_ = false;
   bool debug_ = false;
   bool board_registered_ = false;
@@ -544,6 +659,11 @@ class PeerContext {
 };
 
 uint64_t peerSlotHigh(cudecompHandle_t h, int slot) { return h->peer ? h->peer->slotHigh(slot) : 0; }
+
+void peerPoolCounters(cudecompHandle_t h, int64_t* pool_hits, int64_t* stale_mappings) {
+  *pool_hits = h->peer ? h->peer->poolHits() : 0;
+  *stale_mappings = h->peer ? h->peer->staleMappingsSeen() : 0;
+}
 
 void peerCheckStatus(cudecompHandle_t h) {
   if (h->peer) h->peer->checkStatus();
@@ -706,15 +826,41 @@ void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
     bytes = (size_t)h->boot->allreduceMaxI64((int64_t)bytes);
     bytes = ipcSafeSize(bytes);
     prepareTransports(h, false, true);
-    CD_CHECK_HIP(hipMalloc(&ptr, bytes));
-    try {
-      h->peer->registerRegion(ptr, bytes);
-    } catch (const Error& e) {
-      // Agreed on by all ranks (registerRegion fails collectively).  The buffer is still a valid workspace for the
-      // RCCL / MPI transports; an operation that needs the one-sided transport will report the IPC problem itself.
+    if (void* pooled = h->peer->takeFromPool(bytes)) return pooled;  // (the same decision on every rank)
+    // A new allocation is mapped into every rank and the mappings are VERIFIED (page tags).  The platform can answer
+    // hipIpcOpenMemHandle with the mapping of a predecessor of the allocation (freed, re-created at the same address,
+    // DESIGN.md section 9); such a buffer is set aside -- so that the next attempt gets another address -- and
+    // released once a good one is registered.
+    std::vector<void*> set_aside;
+    std::string failure;
+    for (int attempt = 0; attempt < 4 && !ptr; ++attempt) {
+      void* cand = nullptr;
+      CD_CHECK_HIP(hipMalloc(&cand, bytes));
+      bool stale = false;
+      try {
+        if (h->peer->registerRegion(cand, bytes, &stale)) ptr = cand;
+      } catch (const Error& e) {
+        // Agreed on by all ranks (registerRegion fails collectively): export or import refused.  The same platform
+        // behaviour shows this way too ("invalid argument" / "invalid device pointer" for a re-created allocation), so
+        // another address gets its chance before the library gives up on sharing the workspace.
+        failure = e.what();
+      }
+      if (!ptr) set_aside.push_back(cand);
+    }
+    if (!ptr) {
+      // not shared: still a valid workspace for the RCCL / MPI transports; an operation that needs the one-sided
+      // transport will report the IPC problem itself
+      if (failure.empty()) failure = "every attempt to map the workspace into the other ranks ended with a stale mapping";
+      ptr = set_aside.back();
+      set_aside.pop_back();
+    } else {
+      failure.clear();
+    }
+    for (void* q : set_aside) (void)hipFree(q);
+    if (!failure.empty()) {
       if (h->rank == 0 && !h->ipc_warned) {
         fprintf(stderr, "CUDECOMP:WARN: workspace could not be shared over IPC (%s); one-sided (NVSHMEM*/default MPI*) "
-                        "backends are unavailable with it\n", e.what());
+                        "backends are unavailable with it\n", failure.c_str());
       }
       h->ipc_warned = true;
     }
@@ -724,10 +870,26 @@ void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
   return ptr;
 }
 
+namespace {
+void releaseRegionForReal(cudecompHandle_t h, void* ptr) {
+  h->peer->unregisterRegion(ptr);
+  CD_CHECK_HIP(hipFree(ptr));
+}
+}  // namespace
+
 void workspaceFreeRaw(cudecompHandle_t h, void* ptr) {
   if (h->peer) {
     auto* r = h->peer->find(ptr);
-    if (r && r->base == ptr) h->peer->unregisterRegion(ptr);
+    if (r && r->base == ptr) {
+      // like hipFree, return only when everything this rank enqueued that may touch the buffer is done
+      CD_CHECK_HIP(hipDeviceSynchronize());
+      if (h->peer->poolEnabled()) {
+        for (void* q : h->peer->park(ptr)) releaseRegionForReal(h, q);  // (the same list on every rank)
+        return;
+      }
+      releaseRegionForReal(h, ptr);
+      return;
+    }
   }
   CD_CHECK_HIP(hipFree(ptr));
 }
@@ -838,21 +1000,19 @@ PeerCall peerBegin(cudecompHandle_t h, cudecompCommInfo& ci, bool rendezvous, co
   return call;
 }
 
-namespace {
-
-// chunk for member d (already packed at `src`) -> d's receive area, on copy stream `cs`, which must already wait
-// for the pack; raises landed[d][me] afterwards
-void sendChunk(cudecompHandle_t h, PeerContext& pc, cudecompCommInfo& ci, const PeerCall& call, int d, char* remote,
-               const char* src, size_t bytes, hipStream_t cs) {
-  FlagList ready, landed;
-  ready.add(pc.dReady(ci.barrier_slot, ci.global_ranks[d]));
-  landed.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[d], h->rank));
-  launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, cs);
-  peerCopy(h, remote, src, bytes, cs);
-  launchSignal(call.epoch, landed, cs);
+// One wait for "every receiver's receive area is free" on the CALLER's stream, then an event the copy streams wait
+// for.  No copy stream ever parks a spinning wait kernel: the runtime multiplexes a process's streams onto a handful
+// of hardware queues (GPU_MAX_HW_QUEUES, default 4), and a wait kernel parked on one of them would hold up the copies
+// of every stream that shares its queue.  The pipelined exchange calls this right after the FIRST chunk is packed, so
+// a receiver that is late delays nothing that could have run.
+void peerReadyGate(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& p, const PeerCall& call, hipStream_t stream) {
+  PeerContext& pc = peerOf(h, ci);
+  const int P = ci.nranks;
+  FlagList ready;
+  for (int j = 1; j < P; ++j) ready.add(pc.dReady(ci.barrier_slot, ci.global_ranks[p.schedule_dst[j]]));
+  launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, stream);
+  CD_CHECK_HIP(hipEventRecord(pc.copyEvent(2 * P), stream));  // "go": receivers ready
 }
-
-}  // namespace
 
 // All chunks at once: they are packed (caller), then P-1 concurrent copies,
 // one stream per peer so that every link / SDMA queue is busy, each gated by the receiver's ready flag; `stream`
@@ -861,14 +1021,9 @@ void peerAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan&
                   const PeerCall& call, hipStream_t stream) {
   PeerContext& pc = peerOf(h, ci);
   const int P = ci.nranks, me = ci.rank;
-  // ONE wait for every receiver's ready flag on the caller's stream, then the copies fan out: a wait kernel parked on
-  // a copy stream would hold the hardware queue that stream shares with others (the runtime multiplexes its streams
-  // onto a handful of queues) and delay copies to peers that are ready
-  FlagList ready;
-  for (int j = 1; j < P; ++j) ready.add(pc.dReady(ci.barrier_slot, ci.global_ranks[p.schedule_dst[j]]));
-  launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, stream);
-  hipEvent_t go = pc.copyEvent(2 * P);
-  CD_CHECK_HIP(hipEventRecord(go, stream));  // chunks packed, receivers ready
+  // ONE wait for every receiver's ready flag on the caller's stream, then the copies fan out (see peerReadyGate)
+  peerReadyGate(h, ci, p, call, stream);
+  hipEvent_t go = pc.copyEvent(2 * P);  // chunks packed, receivers ready
   for (int j = 1; j < P; ++j) {
     const int d = p.schedule_dst[j];
     hipStream_t cs = pc.copyStream(j);
@@ -945,9 +1100,60 @@ void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePl
 
 bool peerPipelineAvailable(cudecompHandle_t h, const cudecompCommInfo& ci) { return h->peer && h->peer->usable(ci); }
 
+// CUDECOMP_DEBUG_VERIFY_EXCHANGE=1 (host-synchronous debugging aid): after a one-sided exchange,
+// tell LATE data from data that NEVER ARRIVED HERE.  Every member checksums each chunk it received as soon as its own
+// stream has drained (the landed flags said "complete"), again after a barrier of the communicator (now nothing is in
+// flight anywhere), and compares with the checksum the SENDER takes of the chunk it sent.
+//   first != second            the flag overtook the data (late arrival)
+//   second != sender's         the data did not arrive in this buffer at all (misdirected / lost), or was damaged
+void peerVerifyExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& p, const ExchangeBuffers& b, int es,
+                        bool sender_side_valid, const char* what, hipStream_t stream) {
+  PeerContext& pc = peerOf(h, ci);
+  const int P = ci.nranks, me = ci.rank;
+  CD_CHECK_HIP(hipStreamSynchronize(stream));
+  unsigned long long* dev = nullptr;
+  CD_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(unsigned long long) * 2 * 3 * P));
+  CD_CHECK_HIP(hipMemset(dev, 0, sizeof(unsigned long long) * 2 * 3 * P));
+  auto sums = [&](int pass) {  // pass 0 / 1: incoming chunks; pass 2: outgoing chunks
+    for (int m = 0; m < P; ++m) {
+      const char* ptr = pass < 2 ? b.recv + p.recv_off[m] * es : b.send + p.send_off[m] * es;
+      const size_t bytes = (size_t)(pass < 2 ? p.recv_cnt[m] : p.send_cnt[m]) * es;
+      launchChecksum(ptr, bytes, dev + 2 * (pass * P + m), stream);
+    }
+  };
+  sums(0);
+  if (sender_side_valid) sums(2);
+  CD_CHECK_HIP(hipStreamSynchronize(stream));
+  pc.barrier(ci);
+  sums(1);
+  CD_CHECK_HIP(hipStreamSynchronize(stream));
+  std::vector<unsigned long long> host((size_t)2 * 3 * P);
+  CD_CHECK_HIP(hipMemcpy(host.data(), dev, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(dev);
+  // everybody's "what I sent to member d": [member][d][2]
+  std::vector<unsigned long long> sent((size_t)2 * P * P);
+  ci.boot->allgather(host.data() + (size_t)2 * 2 * P, sent.data(), sizeof(unsigned long long) * 2 * P);
+  for (int s = 0; s < P; ++s) {
+    if (p.recv_cnt[s] == 0) continue;
+    const unsigned long long* r1 = &host[2 * (0 * P + s)];
+    const unsigned long long* r2 = &host[2 * (1 * P + s)];
+    const unsigned long long* ex = &sent[2 * ((size_t)s * P + me)];
+    const bool late = r1[0] != r2[0] || r1[1] != r2[1];
+    const bool wrong = sender_side_valid && (r2[0] != ex[0] || r2[1] != ex[1]);
+    if (late || wrong)
+      fprintf(stderr, "CUDECOMP:VERIFY rank %d %s: chunk from member %d (rank %d, %lld bytes at recv offset %lld): %s%s  "
+                      "[at flag %016llx/%016llx, after barrier %016llx/%016llx, sender %016llx/%016llx]\n",
+              h->rank, what, s, ci.global_ranks[s], (long long)p.recv_cnt[s] * es, (long long)p.recv_off[s] * es,
+              late ? "LATE (changed after the landed flag) " : "", wrong ? "NOT WHAT WAS SENT even after everyone drained" : "",
+              r1[0], r1[1], r2[0], r2[1], ex[0], ex[1]);
+  }
+  (void)me;
+}
+
 // Per-peer pipeline of the one-sided transport (NVSHMEM_PL / MPI_P2P_PL enums): chunk by chunk
 //   pack(d) [caller, event per destination] -> copy to d over xGMI [one stream per peer] -> d unpacks it
-// A copy to d starts as soon as d's receive area is free and d's chunk is packed, and the unpack of the chunk from s
+// A copy to d starts as soon as the receivers are ready (one wait on the caller's stream behind the first pack,
+// peerReadyGate) and d's chunk is packed, and the unpack of the chunk from s
 // is enqueued behind a wait for s's landed flag -- packs, the P-1 link transfers and unpacks overlap, all of it on
 // the device (counterpart of comm_routines.h:427-631 + transpose.h:470-513, 683-744).
 void peerPipelinedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
@@ -955,12 +1161,16 @@ void peerPipelinedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCo
                            hipStream_t stream) {
   PeerContext& pc = peerOf(h, ci);
   const int P = plan.nranks, me = plan.comm_rank;
+  hipEvent_t go = pc.copyEvent(2 * P);  // recorded by peerReadyGate after the first pack: every receiver is ready
   for (int j = 1; j < P; ++j) {
     const int d = plan.schedule_dst[j];
     hipStream_t cs = pc.copyStream(j);
     CD_CHECK_HIP(hipStreamWaitEvent(cs, gd->events[d], 0));  // chunk for d is packed
-    sendChunk(h, pc, ci, call, d, call.remote_recv[d] + plan.remote_recv_off[d] * es, b.send + plan.send_off[d] * es,
-              (size_t)plan.send_cnt[d] * es, cs);
+    CD_CHECK_HIP(hipStreamWaitEvent(cs, go, 0));
+    peerCopy(h, call.remote_recv[d] + plan.remote_recv_off[d] * es, b.send + plan.send_off[d] * es, (size_t)plan.send_cnt[d] * es, cs);
+    FlagList landed;
+    landed.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[d], h->rank));
+    launchSignal(call.epoch, landed, cs);
     CD_CHECK_HIP(hipEventRecord(pc.copyEvent(j), cs));
   }
   for (int j = 0; j < P; ++j) {
@@ -1077,33 +1287,36 @@ int memberOf(const cudecompCommInfo& ci, int global_rank) {
 
 // faces -> neighbours' halo slots.  packed[i] (may be null: face data ready on `stream` already) gates face i.
 // Slot i of mine is filled by neighbour i, who raises landed[me][i]; I fill slot 1-i of neighbour i.
-void peerHaloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x, const PeerCall& call,
-                      hipEvent_t* packed, hipStream_t stream) {
+// one wait for both neighbours' "my halo slots are free" on the caller's stream; returns the event the copy streams
+// wait for (no copy stream parks a wait kernel, see peerReadyGate)
+hipEvent_t haloReadyGate(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x, const PeerCall& call, hipStream_t stream) {
   cudecompCommInfo& ci = gd->comm(x.comm_axis);
   PeerContext& pc = peerOf(h, ci);
-  hipEvent_t ready_ev = nullptr;
-  if (!packed) {
-    // plain sequence: one wait for both neighbours on the caller's stream, then the two copies fan out
-    FlagList both;
-    for (int i = 0; i < 2; ++i)
-      if (x.neighbor[i] != -1 && (i == 0 || x.neighbor[1] != x.neighbor[0])) both.add(pc.dReady(ci.barrier_slot, x.neighbor[i]));
-    launchWait(call.epoch, both, pc.dStatus(), h->peer_timeout_s, stream);
-    ready_ev = pc.copyEvent(2 * ci.nranks + 1);
-    CD_CHECK_HIP(hipEventRecord(ready_ev, stream));
-  }
+  FlagList both;
+  for (int i = 0; i < 2; ++i)
+    if (x.neighbor[i] != -1 && (i == 0 || x.neighbor[1] != x.neighbor[0])) both.add(pc.dReady(ci.barrier_slot, x.neighbor[i]));
+  launchWait(call.epoch, both, pc.dStatus(), h->peer_timeout_s, stream);
+  hipEvent_t ready_ev = pc.copyEvent(2 * ci.nranks + 1);
+  CD_CHECK_HIP(hipEventRecord(ready_ev, stream));
+  return ready_ev;
+}
+
+void peerHaloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange& x, const PeerCall& call,
+                      hipEvent_t* packed, hipEvent_t ready_ev, hipStream_t stream) {
+  cudecompCommInfo& ci = gd->comm(x.comm_axis);
+  PeerContext& pc = peerOf(h, ci);
+  // plain sequence (packed == nullptr): the gate comes after both packs, then the two copies fan out;
+  // overlapped sequence: the caller placed it behind the first pack, each face also waits for its own pack
+  if (!ready_ev) ready_ev = haloReadyGate(h, gd, x, call, stream);
   FlagList incoming;
   for (int i = 0; i < 2; ++i) {
     if (x.neighbor[i] == -1) continue;
     const int m = memberOf(ci, x.neighbor[i]);
     hipStream_t cs = pc.copyStream(i);
-    CD_CHECK_HIP(hipStreamWaitEvent(cs, packed ? packed[i] : ready_ev, 0));
+    if (packed) CD_CHECK_HIP(hipStreamWaitEvent(cs, packed[i], 0));
+    CD_CHECK_HIP(hipStreamWaitEvent(cs, ready_ev, 0));
     FlagList landed;
     landed.add(pc.dLanded(ci.barrier_slot, x.neighbor[i], 1 - i));
-    if (packed) {  // overlapped sequence: each face waits for its own receiver behind its own pack
-      FlagList ready;
-      ready.add(pc.dReady(ci.barrier_slot, x.neighbor[i]));
-      launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, cs);
-    }
     peerCopy(h, call.remote_recv[m] + x.remote_off[i], x.send + x.send_off[i], (size_t)x.bytes, cs);
     launchSignal(call.epoch, landed, cs);
     CD_CHECK_HIP(hipEventRecord(pc.copyEvent(i), cs));
@@ -1142,7 +1355,7 @@ void haloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExchange&
   // before this call; the epoch starts here, i.e. "my halo slots are free" is published after the packs -- harmless,
   // the overlapped variant below publishes it before them.
   const PeerCall call = haloBegin(h, gd, x, backend, stream);
-  peerHaloExchange(h, gd, x, call, nullptr, stream);
+  peerHaloExchange(h, gd, x, call, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1207,11 +1420,13 @@ bool haloExchangePackedOverlapped(cudecompHandle_t h, cudecompGridDesc_t gd, con
   // and every launch saved counts at that size.
   if (x.bytes < kHaloOverlapMinBytes && !h->halo_overlap_force) return false;
   const PeerCall call = haloBegin(h, gd, x, backend, stream);
+  hipEvent_t ready_ev = nullptr;
   for (int i = 0; i < 2; ++i) {
     if (const Move3D* m = moveOf(plan.pre, i)) launchMoves(m, 1, bufs, es, stream, &h->tuning);
     CD_CHECK_HIP(hipEventRecord(packed[i], stream));
+    if (i == 0) ready_ev = haloReadyGate(h, gd, x, call, stream);  // behind the first pack: the second overlaps the wait's tail
   }
-  peerHaloExchange(h, gd, x, call, packed, stream);
+  peerHaloExchange(h, gd, x, call, packed, ready_ev, stream);
   launchMoves(plan.post.data(), (int)plan.post.size(), bufs, es, stream, &h->tuning);
   return true;
 }

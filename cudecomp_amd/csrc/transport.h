@@ -32,6 +32,8 @@ void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer);
 
 // highest counter value found in row `slot` of the shared board that involves this rank (0 without a board)
 uint64_t peerSlotHigh(cudecompHandle_t h, int slot);
+// cudecompMalloc calls served from the pool of released workspaces / new IPC mappings found stale (0, 0 without a peer transport)
+void peerPoolCounters(cudecompHandle_t h, int64_t* pool_hits, int64_t* stale_mappings);
 // throws if a device-side wait of an earlier one-sided exchange gave up (dead peer)
 void peerCheckStatus(cudecompHandle_t h);
 // one-direction copy rate to the next rank through both copy engines (collective; fills h->link_gbps_*)
@@ -81,12 +83,18 @@ void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInf
 void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, void* const bufs[3], int es,
                      const PeerCall& call, hipStream_t stream);
 
-// Per-peer pipeline of the one-sided transport.  Precondition: gd->events[d] was recorded on `stream` after the pack
-// kernel of destination d.  Launches the unpack moves itself.
+// Per-peer pipeline of the one-sided transport.  Preconditions: gd->events[d] was recorded on `stream` after the pack
+// kernel of destination d, and peerReadyGate() was enqueued on `stream` (after the first pack).  Launches the unpack
+// moves itself.
+void peerReadyGate(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, const PeerCall& call, hipStream_t stream);
 bool peerPipelineAvailable(cudecompHandle_t h, const cudecompCommInfo& ci);
 void peerPipelinedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
                            void* const bufs[3], const ExchangeBuffers& b, int es, const PeerCall& call,
                            hipStream_t stream);
+
+// debugging aid (CUDECOMP_DEBUG_VERIFY_EXCHANGE=1): host-synchronous check of what a one-sided exchange delivered
+void peerVerifyExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, const ExchangeBuffers& b, int es,
+                        bool sender_side_valid, const char* what, hipStream_t stream);
 
 // Per-peer variant used by the pipelined backends: exchange with the given members only.  Waits for
 // pack_done[dst] before sending to dst and makes `stream` wait for the arrival of each chunk.

@@ -210,7 +210,21 @@ void runTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, TransposeOp op, voi
     perfMark(pev, 3, stream);
     return;
   }
+  const int64_t direct_before = gd->direct_puts;
   executeTranspose(h, gd, plan, key, bufs, es, backend, inplace, traits.pipelined, pev, stream);
+  if (h->debug_verify_exchange && plan.exchange && usesPeerTransport(h, backend)) {
+    static const char* names[4] = {"XToY", "YToZ", "ZToY", "YToX"};
+    cudecompCommInfo& ci = gd->comm(plan.comm_axis);
+    ExchangeBuffers xb;
+    xb.send = static_cast<char*>(bufs[plan.send_buf]) + plan.send_base * es;
+    xb.recv = static_cast<char*>(bufs[plan.recv_buf]) + plan.recv_base * es;
+    // the sender's copy of a chunk is still there afterwards unless the fused put never materialised it or an in-place
+    // unpack has overwritten the pencil it was sent from
+    const bool fused = backend == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_SM;
+    const bool sender_valid = !fused && !(inplace && plan.send_buf != BUF_WORK);
+    if (gd->direct_puts == direct_before)  // (a direct put has no receive area to look at)
+      peerVerifyExchange(h, ci, plan, xb, es, sender_valid, names[(int)op], stream);
+  }
 }
 
 namespace {
@@ -303,13 +317,20 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
       CD_CHECK_HIP(hipGraphLaunch(exec, stream));
       gd->graph_launches++;
     } else {
+      bool gated = !one_sided;
       for (const Move3D& m : plan.pack) {
         launchMoves(&m, 1, bufs, es, stream, &h->tuning);
         CD_CHECK_HIP(hipEventRecord(gd->events[m.peer], stream));
+        if (!gated) {  // the receivers' "ready" is awaited once, behind the first pack (transport.cc: peerReadyGate)
+          peerReadyGate(h, ci, plan, call, stream);
+          gated = true;
+        }
       }
+      if (!gated) peerReadyGate(h, ci, plan, call, stream);
     }
   } else {
     for (int d = 0; d < P; ++d) CD_CHECK_HIP(hipEventRecord(gd->events[d], stream));
+    if (one_sided) peerReadyGate(h, ci, plan, call, stream);
   }
   if (one_sided) {
     // packs, link transfers and unpacks overlap chunk by chunk, ordered by the pairwise flags on the device

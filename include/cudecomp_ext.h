@@ -130,6 +130,9 @@ typedef struct {
   int64_t graphs_captured, graph_launches;
   int64_t local, rccl, mpi, peer_barrier, peer_fused, peer_pipelined;
   int64_t direct_puts; /* peer_fused transposes that wrote straight into the peers' output pencils (no unpack) */
+  /* per HANDLE (not per descriptor): cudecompMalloc calls served from the pool of released workspaces, and new IPC
+   * mappings whose page tags did not read back (stale mapping: the workspace was re-created at another address) */
+  int64_t workspace_pool_hits, stale_ipc_mappings;
 } cudecompExtCounters_t;
 cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
                                         cudecompExtCounters_t* counters);

@@ -5,9 +5,11 @@
  * only, benchmark/benchmark.cu:139, 435-447); this is the "host-MPI CPU path" the measurement is quoted next to.
  * TEST / MEASUREMENT INFRASTRUCTURE ONLY -- nothing in the product links or calls it.
  *
- *   mpirun -np R ./cpu_mpi_cycle N prow pcol contiguous(0|1) warmup trials
- * prints one JSON line on rank 0: cycle time (max over ranks, average of the trials, MPI_Wtime after a barrier as
- * benchmark.cu:503-505, 587-590 times the GPU path) and effective GB/s = 4 * N^3 * 8 B / t. */
+ *   mpirun -np R ./cpu_mpi_cycle N prow pcol contiguous(0|1) warmup trials [kind: 0 fp32 | 1 fp64 (default) | 2 c64 | 3 c128]
+ * prints one JSON line on rank 0: cycle time (max over ranks, min / max / avg / std over the trials, MPI_Wtime after a
+ * barrier as benchmark.cu:503-505, 587-590 times the GPU path) and effective GB/s = 4 * N^3 * element bytes / t.
+ * BASELINE config 1 is `mpirun -np 2 ./cpu_mpi_cycle 256 2 1 0 3 5 0` (256^3 fp32 slab, 2 ranks). */
+#include <math.h>
 #include <mpi.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,13 +26,16 @@ static void exchange(void* user, const char* send, const int64_t* send_cnt, cons
   (void)comm_rank;
   comms_t* c = (comms_t*)user;
   int sc[ORC_MAX_COMM], so[ORC_MAX_COMM], rc[ORC_MAX_COMM], ro[ORC_MAX_COMM];
-  for (int i = 0; i < P; ++i) { /* counts in 8-byte words keep 32-bit MPI counts in range for the sample sizes */
-    sc[i] = (int)(send_cnt[i] * es / 8);
-    so[i] = (int)(send_off[i] * es / 8);
-    rc[i] = (int)(recv_cnt[i] * es / 8);
-    ro[i] = (int)(recv_off[i] * es / 8);
+  /* counts in words of min(es, 8) bytes keep 32-bit MPI counts in range for the sample sizes */
+  const int w = es < 8 ? es : 8;
+  for (int i = 0; i < P; ++i) {
+    sc[i] = (int)(send_cnt[i] * es / w);
+    so[i] = (int)(send_off[i] * es / w);
+    rc[i] = (int)(recv_cnt[i] * es / w);
+    ro[i] = (int)(recv_off[i] * es / w);
   }
-  MPI_Alltoallv(send, sc, so, MPI_DOUBLE, recv, rc, ro, MPI_DOUBLE, comm_axis == 0 ? c->col : c->row);
+  const MPI_Datatype t = (w == 4) ? MPI_FLOAT : MPI_DOUBLE;
+  MPI_Alltoallv(send, sc, so, t, recv, rc, ro, t, comm_axis == 0 ? c->col : c->row);
 }
 
 int main(int argc, char** argv) {
@@ -45,6 +50,13 @@ int main(int argc, char** argv) {
   }
   const int n = atoi(argv[1]), pr = atoi(argv[2]), pc = atoi(argv[3]), contiguous = atoi(argv[4]);
   const int warmup = atoi(argv[5]), trials = atoi(argv[6]);
+  const int kind = argc > 7 ? atoi(argv[7]) : 1;
+  static const int kind_bytes[4] = {4, 8, 8, 16};
+  if (kind < 0 || kind > 3) {
+    if (rank == 0) fprintf(stderr, "kind must be 0..3\n");
+    MPI_Finalize();
+    return 2;
+  }
   if (pr * pc != nranks) {
     if (rank == 0) fprintf(stderr, "process grid %d x %d does not match %d ranks\n", pr, pc, nranks);
     MPI_Finalize();
@@ -68,38 +80,43 @@ int main(int argc, char** argv) {
     orc_pencil_info(&g, rank, ax, NULL, NULL, &p[ax]);
     if (p[ax].size > nel) nel = p[ax].size;
   }
-  const int es = 8;
+  const int es = kind_bytes[kind];
   const int64_t ws = orc_transpose_workspace_size(&g);
-  double* a = (double*)malloc((size_t)nel * es);
-  double* b = (double*)malloc((size_t)nel * es);
-  double* w = (double*)malloc((size_t)(ws > 0 ? ws : 1) * es);
+  char* a = (char*)malloc((size_t)nel * es);
+  char* b = (char*)malloc((size_t)nel * es);
+  char* w = (char*)malloc((size_t)(ws > 0 ? ws : 1) * es);
   if (!a || !b || !w) return 4;
-  orc_fill_pencil(&p[0], gdims, 1, 0, a);
+  orc_fill_pencil(&p[0], gdims, kind, 0, a);
   memset(b, 0, (size_t)nel * es);
   memset(w, 0, (size_t)(ws > 0 ? ws : 1) * es);
-  double* ref = (double*)malloc((size_t)p[0].size * es);
+  char* ref = (char*)malloc((size_t)p[0].size * es);
   if (!ref) return 4;
   memcpy(ref, a, (size_t)p[0].size * es);
 
   const int ax_of[4] = {0, 1, 2, 1}, dir_of[4] = {+1, +1, -1, -1};
-  double total = 0;
+  double total = 0, tmin = 1e30, tmax = 0, sq = 0;
   for (int t = 0; t < warmup + trials; ++t) {
     MPI_Barrier(MPI_COMM_WORLD);
     const double t0 = MPI_Wtime();
-    double *cur = a, *nxt = b;
+    char *cur = a, *nxt = b;
     for (int op = 0; op < 4; ++op) {
       if (orc_transpose_rank(&g, rank, ax_of[op], dir_of[op], es, cur, nxt, w, NULL, NULL, NULL, NULL, 0, exchange,
                              &comms) != ORC_OK) {
         fprintf(stderr, "rank %d: transpose %d failed\n", rank, op);
         MPI_Abort(MPI_COMM_WORLD, 5);
       }
-      double* tmp = cur;
+      char* tmp = cur;
       cur = nxt;
       nxt = tmp;
     }
     double dt = MPI_Wtime() - t0, dmax = 0;
     MPI_Allreduce(&dt, &dmax, 1, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD);
-    if (t >= warmup) total += dmax;
+    if (t >= warmup) {
+      total += dmax;
+      sq += dmax * dmax;
+      if (dmax < tmin) tmin = dmax;
+      if (dmax > tmax) tmax = dmax;
+    }
   }
   /* four hops, out of place: the X pencil must be back in `a`, bit for bit */
   int ok = memcmp(ref, a, (size_t)p[0].size * es) == 0, all_ok = 0;
@@ -107,10 +124,12 @@ int main(int argc, char** argv) {
   MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
   if (rank == 0) {
     const double sec = total / trials;
+    const double var = sq / trials - sec * sec;
     printf("{\"n\": %d, \"ranks\": %d, \"pdims\": [%d, %d], \"contiguous\": %d, \"warmup\": %d, \"trials\": %d, "
-           "\"cycle_s\": %.6f, \"gbps\": %.4f, \"round_trip_ok\": %s}\n",
-           n, nranks, pr, pc, contiguous, warmup, trials, sec, 4.0 * n * (double)n * n * 8 / sec / 1e9,
-           all_ok ? "true" : "false");
+           "\"element_bytes\": %d, \"cycle_s\": %.6f, \"cycle_s_min\": %.6f, \"cycle_s_max\": %.6f, \"cycle_s_std\": %.6f, "
+           "\"gbps\": %.4f, \"round_trip_ok\": %s}\n",
+           n, nranks, pr, pc, contiguous, warmup, trials, es, sec, tmin, tmax, var > 0 ? sqrt(var) : 0.0,
+           4.0 * n * (double)n * n * es / sec / 1e9, all_ok ? "true" : "false");
   }
   free(a);
   free(b);

@@ -9,13 +9,20 @@
 //          bit 3: keep a spinning 1-wave kernel on EXTRA_STREAMS streams during the writes (queue pressure, as the
 //                 library's wait kernels produce it)
 //          bit 4: the parent process holds a HIP context of its own (a ninth process on the device)
+//          bit 5: never hipFree a buffer before the end (new allocations cannot reuse an address or a handle)
+//          bit 6: keep the buffers, only CLOSE and RE-OPEN the peers' mappings in every iteration
+//          bit 7: print the IPC handle bytes of rank 0's buffer in every iteration
+//          bit 8: importers never CLOSE a mapping (the owners still free and re-create their buffers)
+//          bit 9: the owner sleeps 20 ms between hipFree and the next hipMalloc (is it a race with a deferred release?)
 //
 // Children are forked before HIP starts.  Every iteration: each rank owns `buf` (N slices); rank r writes slice r of
 // EVERY rank's buf with f(r, iteration, index); after a device sync + barrier every rank checks its whole buf on the
 // device.  A mismatch is reported with the byte range, its alignment and what the cells hold instead (the fill
 // pattern of this iteration = "never arrived here"; the previous iteration's data = "stale").
 #include <hip/hip_runtime.h>
+#include <signal.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -28,12 +35,15 @@
 #include <vector>
 
 static int g_me = -1;
+struct Shared;
+static Shared* g_sh = nullptr;
 #define CK(x)                                                                                  \
   do {                                                                                         \
     hipError_t e_ = (x);                                                                       \
     if (e_ != hipSuccess) {                                                                    \
       printf("[%d] %s:%d %s -> %s\n", g_me, __FILE__, __LINE__, #x, hipGetErrorString(e_));   \
       fflush(stdout);                                                                          \
+      if (g_sh) g_sh->abort_all.store(1);                                                      \
       _exit(2);                                                                                \
     }                                                                                          \
   } while (0)
@@ -44,6 +54,7 @@ struct Shared {
   hipIpcMemHandle_t handle[kMaxProcs];
   std::atomic<uint64_t> bad_total;
   std::atomic<uint64_t> stop_spin;
+  std::atomic<uint64_t> abort_all;
 };
 
 using u64 = unsigned long long;
@@ -95,11 +106,18 @@ static void barrier(Shared* sh, int n, uint64_t& epoch) {
   ++epoch;
   sh->arrive[g_me].store(epoch, std::memory_order_release);
   for (int p = 0; p < n; ++p)
-    while (sh->arrive[p].load(std::memory_order_acquire) < epoch) std::this_thread::yield();
+    while (sh->arrive[p].load(std::memory_order_acquire) < epoch) {
+      if (sh->abort_all.load()) _exit(3);  // a sibling failed: do not wait for it forever
+      std::this_thread::yield();
+    }
 }
 
 static int child(Shared* sh, int me, int n, int iters, int mode, size_t kib, int extra_streams) {
   g_me = me;
+  g_sh = sh;
+  prctl(PR_SET_PDEATHSIG, SIGKILL);  // never outlive the launcher (a timeout kills only the parent)
+  const bool leak = mode & 32, reopen_only = mode & 64, show = mode & 128, no_close = mode & 256, nap = mode & 512;
+  std::vector<u64*> parked;
   const bool remap = mode & 1, use_memcpy = mode & 2, wt = mode & 4, spin = mode & 8;
   CK(hipSetDevice(0));
   uint64_t epoch = 0;
@@ -121,10 +139,17 @@ static int child(Shared* sh, int me, int n, int iters, int mode, size_t kib, int
   auto open_all = [&](u64 iter) {
     // sizes wander a little so that the allocator does not hand back exactly the same block every time
     const size_t bytes = slice * n * 8 + ((iter % 3) << 16);
-    CK(hipMalloc(&buf, bytes));
+    if (!(reopen_only && buf)) CK(hipMalloc(&buf, bytes));
     fill_k<<<256, 256>>>(buf, slice * n, fillValue(me, iter));
     CK(hipDeviceSynchronize());
     CK(hipIpcGetMemHandle(&sh->handle[me], buf));
+    if (show && me == 0) {
+      const unsigned char* hb = reinterpret_cast<const unsigned char*>(&sh->handle[me]);
+      printf("[0] iter %llu buf %p handle", (u64)iter, (void*)buf);
+      for (int k = 0; k < 64; ++k) printf("%s%02x", k % 8 ? "" : " ", hb[k]);
+      printf("\n");
+      fflush(stdout);
+    }
     barrier(sh, n, epoch);
     for (int p = 0; p < n; ++p) {
       if (p == me) {
@@ -141,10 +166,13 @@ static int child(Shared* sh, int me, int n, int iters, int mode, size_t kib, int
     CK(hipDeviceSynchronize());
     barrier(sh, n, epoch);
     for (int p = 0; p < n; ++p)
-      if (p != me) CK(hipIpcCloseMemHandle(remote[p]));
+      if (p != me && !no_close) CK(hipIpcCloseMemHandle(remote[p]));
     barrier(sh, n, epoch);
-    CK(hipFree(buf));
+    if (reopen_only) return;
+    if (leak) parked.push_back(buf);
+    else CK(hipFree(buf));
     buf = nullptr;
+    if (nap) std::this_thread::sleep_for(std::chrono::milliseconds(20));
   };
   CK(hipMalloc(&src, slice * 8));
   if (!remap) open_all(0);
@@ -187,6 +215,8 @@ static int child(Shared* sh, int me, int n, int iters, int mode, size_t kib, int
     for (int w = 0; w < n; ++w) {
       if (!got[w].bad) continue;
       my_bad += got[w].bad;
+      static int reports = 0;
+      if (++reports > 6) continue;
       const u64 b0 = got[w].first * 8, b1 = (got[w].last + 1) * 8;
       printf("[%d] iter %d: slice written by %d: %llu bad u64 in bytes [%llu, %llu) of my buffer (span %llu KiB, start %% 64K = %llu, "
              "%% 4K = %llu); %llu hold this iteration's fill (never arrived), %llu hold the previous iteration's data (stale)\n",
@@ -207,6 +237,7 @@ static int child(Shared* sh, int me, int n, int iters, int mode, size_t kib, int
   }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (!remap) close_all();
+  for (u64* q : parked) CK(hipFree(q));
   sh->bad_total.fetch_add(my_bad);
   barrier(sh, n, epoch);
   if (me == 0) {

@@ -669,3 +669,32 @@ def link_info(rank, nranks, args):
     cd.cudecompFree(h, gd, work)
     cd.cudecompGridDescDestroy(h, gd)
     return info
+
+
+def pool_behaviour(rank, nranks, args):
+    """cudecompMalloc / cudecompFree with the pool of released workspaces: a freed workspace is handed out again for a
+    request it fits (same pointer, no new IPC mappings), a larger request gets a new one, and transposes are exact on
+    recycled workspaces of several descriptors in a row (every cell)."""
+    h, gd, g = _setup(rank, nranks, args)
+    es = 8
+    ws = cd.cudecompGetTransposeWorkspaceSize(h, gd) * es
+    c0 = cd.cudecompExtGetCounters(h, gd)
+    p1 = cd.cudecompMalloc(h, gd, ws)
+    cd.cudecompFree(h, gd, p1)
+    p2 = cd.cudecompMalloc(h, gd, ws)          # same size: must come from the pool when it is on
+    cd.cudecompFree(h, gd, p2)
+    p3 = cd.cudecompMalloc(h, gd, 3 * ws + (1 << 20))  # too large for the parked one
+    p4 = cd.cudecompMalloc(h, gd, ws)          # the parked one again, while p3 is live
+    c1 = cd.cudecompExtGetCounters(h, gd)
+    out = {"same_pointer": p1 == p2 == p4, "distinct_large": p3 not in (p1, p2, p4),
+           "pool_hits": c1["workspace_pool_hits"] - c0["workspace_pool_hits"], "stale": c1["stale_ipc_mappings"]}
+    cd.cudecompFree(h, gd, p3)
+    cd.cudecompFree(h, gd, p4)
+    cd.cudecompGridDescDestroy(h, gd)
+    failures = []
+    for k in range(args.get("descriptors", 3)):  # fresh descriptor + "fresh" (recycled) workspace each time
+        pd = args["pdims"] if k % 2 == 0 else (args["pdims"][1], args["pdims"][0])
+        r = cycle_exact(rank, nranks, dict(args, pdims=pd))
+        failures += r["failures"]
+    out["failures"] = failures
+    return out
