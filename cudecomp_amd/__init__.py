@@ -84,7 +84,9 @@ class ExtTransposePlan(C.Structure):
                 ("remote_recv_off", C.c_int64 * EXT_MAX_MEMBERS),
                 ("member_global_rank", C.c_int32 * EXT_MAX_MEMBERS), ("schedule_dst", C.c_int32 * EXT_MAX_MEMBERS),
                 ("pack", ExtMove * EXT_MAX_MEMBERS), ("unpack", ExtMove * EXT_MAX_MEMBERS),
-                ("n_direct", C.c_int32), ("reserved2", C.c_int32), ("direct", ExtMove * EXT_MAX_MEMBERS)]
+                ("n_direct", C.c_int32), ("reserved2", C.c_int32), ("direct", ExtMove * EXT_MAX_MEMBERS),
+                ("stage_axis", C.c_int32), ("reserved3", C.c_int32), ("stage_limit", C.c_int64),
+                ("send_n", C.c_int64 * EXT_MAX_MEMBERS), ("recv_n", C.c_int64 * EXT_MAX_MEMBERS)]
 
 
 class ExtHaloPlan(C.Structure):
@@ -121,7 +123,7 @@ API_SYMBOLS = [
     "cudecompUpdateHalosY", "cudecompUpdateHalosZ",
 ]
 EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecompExtMove3D",
-               "cudecompExtGetTransposeTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
+               "cudecompExtGetTransposeTimings", "cudecompExtGetHaloTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
                "cudecompExtPlanTranspose", "cudecompExtPlanHalo", "cudecompExtPencilInfo", "cudecompExtShiftedRank",
                "cudecompExtWorkspaceSizes", "cudecompExtGetLinkInfo", "cudecompExtLastKernelName",
                "cudecompExtRunLocalPhases"]
@@ -188,6 +190,7 @@ def lib():
         L.cudecompExtGetHaloPlan.argtypes = [vp, vp, i32, pi32, C.POINTER(C.c_bool), i32, pi32, i32,
                                              C.POINTER(ExtHaloPlan)]
         L.cudecompExtGetTransposeTimings.argtypes = [vp, vp, i32, C.POINTER(ExtTransposeTimings)]
+        L.cudecompExtGetHaloTimings.argtypes = [vp, vp, i32, i32, C.POINTER(ExtTransposeTimings)]
         L.cudecompExtPeerProbe.argtypes = [vp, vp, C.c_size_t, pi32]
         L.cudecompExtGetCounters.argtypes = [vp, vp, C.POINTER(ExtCounters)]
         L.cudecompExtPlanTranspose.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, pi32, pi32, C.c_bool, i32,
@@ -345,6 +348,12 @@ def cudecompExtGetHaloPlan(handle, gd, axis, halo_extents, halo_periods, dim, pa
     _check(lib().cudecompExtGetHaloPlan(handle, gd, axis, _i3(halo_extents), _b3(halo_periods), dim, _i3(padding),
                                         backend_override, C.byref(p)), "cudecompExtGetHaloPlan")
     return p
+
+
+def cudecompExtGetHaloTimings(handle, gd, axis, dim):
+    t = ExtTransposeTimings()
+    _check(lib().cudecompExtGetHaloTimings(handle, gd, axis, dim, C.byref(t)), "cudecompExtGetHaloTimings")
+    return {k: getattr(t, k) for k, _ in ExtTransposeTimings._fields_}
 
 
 def cudecompExtGetTransposeTimings(handle, gd, op):

@@ -380,6 +380,11 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     if (const char* v = std::getenv("CUDECOMP_RCCL_NATIVE_ALLTOALL")) h->rccl_native_alltoall = std::strtol(v, nullptr, 10) != 0;
     h->direct_put = !envIsOne("CUDECOMP_DISABLE_DIRECT_PUT");
     h->debug_verify_exchange = envIsOne("CUDECOMP_DEBUG_VERIFY_EXCHANGE");
+    if (const char* v = std::getenv("CUDECOMP_PIPELINE_STAGES")) {
+      const long k = std::strtol(v, nullptr, 10);
+      if (k >= 1 && k <= 15) h->pipeline_stages = (int)k;
+      else if (h->rank == 0) printf("CUDECOMP:WARN: Invalid CUDECOMP_PIPELINE_STAGES value (%s); expected 1..15.\n", v);
+    }
     if (const char* v = std::getenv("CUDECOMP_PEER_TIMEOUT")) {
       const double t = std::strtod(v, nullptr);
       if (t > 0) h->peer_timeout_s = t;

@@ -1,4 +1,5 @@
 // ext.cc -- cudecomp_ext.h: plan introspection and a single-move kernel entry for test harnesses.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -60,6 +61,12 @@ void exportTransposePlan(const TransposePlan& p, const std::vector<int>& global_
     for (size_t i = 0; i < p.unpack.size(); ++i) exportMove(p.unpack[i], &out->unpack[i]);
     out->n_direct = (int32_t)p.direct.size();
     for (size_t i = 0; i < p.direct.size(); ++i) exportMove(p.direct[i], &out->direct[i]);
+    out->stage_axis = p.stage_axis;
+    out->stage_limit = p.stage_limit;
+    for (int i = 0; i < p.nranks && p.exchange; ++i) {
+      out->send_n[i] = p.send_n[i];
+      out->recv_n[i] = p.recv_n[i];
+    }
 }
 
 void exportHaloPlan(const HaloPlan& p, cudecompExtHaloPlan_t* out) {
@@ -160,6 +167,28 @@ cudecompResult_t cudecompExtGetTransposeTimings(cudecompHandle_t handle, cudecom
     if (!gd || !gd->initialized || gd->handle != handle) CD_INVALID_USAGE("invalid grid descriptor");
     if (!out || op < 0 || op > 3) CD_INVALID_USAGE("bad argument");
     const TransposeTimings t = perfCollect(gd, op);
+    out->calls = t.calls;
+    out->samples = t.samples;
+    out->total_ms = t.total_ms;
+    out->pack_ms = t.pack_ms;
+    out->exchange_ms = t.exchange_ms;
+    out->unpack_ms = t.unpack_ms;
+    out->pencil_bytes = t.pencil_bytes;
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtGetHaloTimings(cudecompHandle_t handle, cudecompGridDesc_t gd, int32_t axis, int32_t dim,
+                                           cudecompExtTransposeTimings_t* out) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    if (!gd || !gd->initialized || gd->handle != handle) CD_INVALID_USAGE("invalid grid descriptor");
+    if (!out || axis < 0 || axis > 2 || dim < 0 || dim > 2) CD_INVALID_USAGE("bad argument");
+    const TransposeTimings t = perfCollectHalo(gd, axis, dim);
     out->calls = t.calls;
     out->samples = t.samples;
     out->total_ms = t.total_ms;
@@ -359,13 +388,26 @@ cudecompResult_t cudecompExtRunLocalPhases(const cudecompExtGridSpec_t* grid, in
     void* bufs[3] = {input, output, work};
     KernelTuning t;
     if (const char* v = std::getenv("CUDECOMP_INTERLEAVE_ROWS")) t.interleave_rows = (int)std::strtol(v, nullptr, 10);
-    // the launches of the executor: one batched launch per phase, or one launch per peer when the exchange is pipelined
+    // the launches of the executor: one batched launch per phase; pipelined: one launch per STAGE with all peers in it
+    // for the one-sided transport (transport.cc: peerStagedExchange), one launch per PEER for RCCL / MPI (the reference's
+    // pipeline, transpose.h:470-513, 683-744)
+    int stages = 4;
+    if (const char* v = std::getenv("CUDECOMP_PIPELINE_STAGES")) stages = (int)std::strtol(v, nullptr, 10);
+    const int K = (int)std::max<i64>(1, std::min<i64>({(i64)stages, p.stage_limit, (i64)kFlagDone}));
     auto run = [&](const std::vector<Move3D>& moves) {
       if (moves.empty()) return;
-      if (traits.pipelined)
+      if (traits.pipelined && traits.symmetric_recv && p.exchange) {
+        std::vector<Move3D> part;
+        for (int k = 0; k < K; ++k) {
+          part.clear();
+          for (const Move3D& m : moves) part.push_back(stageOfMove(m, p.stage_axis, k, K));
+          launchMoves(part.data(), (int)part.size(), bufs, es, stream, &t);
+        }
+      } else if (traits.pipelined) {
         for (const Move3D& m : moves) launchMoves(&m, 1, bufs, es, stream, &t);
-      else
+      } else {
         launchMoves(moves.data(), (int)moves.size(), bufs, es, stream, &t);
+      }
     };
     if (phases & 1) run(p.pack);
     if (phases & 2) run(p.unpack);

@@ -48,13 +48,18 @@ struct FlagList {
   unsigned long long* f[kMaxFlags];
   void add(unsigned long long* p) { f[n++] = p; }
 };
-// epoch (device memory) += 1; *ready (may be null) = epoch
+// Flags hold  call number * kFlagScale + step  (monotonic): step 0 = the call has begun, 1 .. kFlagScale-2 = that many
+// stages of a staged exchange have landed, kFlagDone = everything of the call has landed.
+constexpr unsigned long long kFlagScale = 16;
+constexpr int kFlagBegun = 0, kFlagDone = (int)kFlagScale - 1;
+// epoch (device memory) += 1; *ready (may be null) = epoch * kFlagScale
 void launchEpochBegin(unsigned long long* epoch, unsigned long long* ready, hipStream_t stream);
-// every flag = *epoch
-void launchSignal(const unsigned long long* epoch, const FlagList& flags, hipStream_t stream);
-// returns (on the stream) when every flag >= *epoch; after timeout_s seconds writes a code to *status and gives up
+// every flag = *epoch * kFlagScale + step
+void launchSignal(const unsigned long long* epoch, const FlagList& flags, hipStream_t stream, int step = kFlagDone);
+// returns (on the stream) when every flag >= *epoch * kFlagScale + step; after timeout_s seconds writes a code to *status
+// and gives up
 void launchWait(const unsigned long long* epoch, const FlagList& flags, unsigned long long* status, double timeout_s,
-                hipStream_t stream);
+                hipStream_t stream, int step = kFlagDone);
 
 // stamp / verify the first word of every 4-KiB page of a shared buffer (see sync.hip)
 void launchTagPages(void* base, size_t bytes, unsigned long long seed, hipStream_t stream);

@@ -418,6 +418,38 @@ TransposeTimings perfCollect(cudecompGridDesc_t gd, int op) {
   return t;
 }
 
+// the same for halo updates: all retained samples of (pencil axis, dim); the three phases are pack / exchange / unpack
+// in the plain sequence (CUDECOMP_DISABLE_HALO_OVERLAP=1) and [0, whole update, 0] in the overlapped one
+TransposeTimings perfCollectHalo(cudecompGridDesc_t gd, int axis, int dim) {
+  TransposeTimings t;
+  bool any = false;
+  for (const auto& kv : gd->perf_halo)
+    if (std::get<0>(kv.first) == axis && std::get<1>(kv.first) == dim) {
+      any = any || !kv.second.ring.empty();
+      t.calls += kv.second.calls;
+      t.pencil_bytes = kv.second.wire_bytes;
+    }
+  if (!any) return t;
+  (void)hipDeviceSynchronize();
+  for (const auto& kv : gd->perf_halo) {
+    if (std::get<0>(kv.first) != axis || std::get<1>(kv.first) != dim) continue;
+    const Series s = readSeries(kv.second);
+    for (size_t i = 0; i < s.total.size(); ++i) {
+      t.pack_ms += s.first[i];
+      t.exchange_ms += s.exchange[i];
+      t.unpack_ms += s.last[i];
+      t.samples++;
+    }
+  }
+  if (t.samples) {
+    t.pack_ms /= t.samples;
+    t.exchange_ms /= t.samples;
+    t.unpack_ms /= t.samples;
+    t.total_ms = t.pack_ms + t.exchange_ms + t.unpack_ms;
+  }
+  return t;
+}
+
 void perfReset(cudecompGridDesc_t gd) {
   for (auto& kv : gd->perf_transpose) {
     for (auto& s : kv.second.ring) s.used = false;

@@ -129,6 +129,12 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
   if (!skip_pack && (skip_unpack || (b.order[2] == ax.a && !orders_equal))) W = b.order;
 
   p.exchange = true;
+  // staging: all chunks are cut along their slowest wire dim.  Its extent is splits_a[d] (chunk for d) when that dim is
+  // ax_a, the sender's slab splits_b[s] when it is ax_b, and the common extent along ax_c otherwise.
+  p.stage_axis = W[2];
+  if (W[2] == ax.a) p.stage_limit = *std::min_element(splits_a.begin(), splits_a.end());
+  else if (W[2] == ax.b) p.stage_limit = *std::min_element(splits_b.begin(), splits_b.end());
+  else p.stage_limit = Sa[ax.c];
   p.send_buf = skip_pack ? BUF_IN : BUF_WORK;
   p.send_base = 0;
   p.recv_buf = skip_unpack ? BUF_OUT : BUF_WORK;
@@ -149,6 +155,12 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
     p.recv_cnt[i] = splits_b[i] * Sb[ax.a] * Sb[ax.c];
     p.recv_off[i] = off_b[i] * Sb[ax.a] * Sb[ax.c];
     p.remote_recv_off[i] = off_b[me] * splits_a[i] * Sa[ax.c];  // = member i's recv_off[me]
+  }
+  p.send_n.resize(P);
+  p.recv_n.resize(P);
+  for (int i = 0; i < P; ++i) {
+    p.send_n[i] = (p.stage_axis == ax.a) ? splits_a[i] : Sa[p.stage_axis];
+    p.recv_n[i] = (p.stage_axis == ax.b) ? splits_b[i] : Sb[p.stage_axis];
   }
 
   p.schedule_dst.resize(P);
@@ -190,6 +202,15 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
     }
   }
   return p;
+}
+
+Move3D stageOfMove(const Move3D& m, int axis, int k, int K) {
+  Move3D r = m;
+  const i64 n = m.extent[axis], lo = n * k / K, hi = n * (k + 1) / K;
+  r.extent[axis] = hi - lo;
+  r.src_off += lo * m.ss[axis];
+  r.dst_off += lo * m.ds[axis];
+  return r;
 }
 
 HaloPlan buildHaloPlan(const GridShape& g, int rank, int axis, int dim, const int32_t* halo, const bool* periods,

@@ -59,6 +59,13 @@ struct TransposePlan {
   std::vector<i64> send_cnt, send_off, recv_cnt, recv_off;
   std::vector<i64> remote_recv_off;  // where MY chunk lands in member d's receive area (one-sided transports)
   std::vector<int> schedule_dst, schedule_src;  // pairwise peer order, entry 0 = self
+  // Staged exchange (one-sided pipelined transports): every chunk is a dense block whose SLOWEST wire dim is the global
+  // axis `stage_axis`; cutting all chunks into the same number of ranges along it gives sub-chunks that are contiguous
+  // in the send and receive areas.  stage_limit = the smallest extent any chunk of the communicator has along that axis
+  // (the same number on every member: an upper bound for the number of stages everybody can agree on without talking).
+  int stage_axis = 2;
+  i64 stage_limit = 1;
+  std::vector<i64> send_n, recv_n;  // extent along stage_axis of the chunk for member d / from member s
 
   // Direct-to-destination put (one-sided transports, out of place): move `direct[j]` takes the slab of my input that
   // belongs to member direct[j].peer and writes it straight into THAT member's output pencil, in its final layout
@@ -91,6 +98,9 @@ struct HaloPlan {
 
 HaloPlan buildHaloPlan(const GridShape& g, int rank, int axis, int dim, const int32_t* halo, const bool* periods,
                        const int32_t* pad, bool force_packed, bool self_exchange = false);
+
+// range k of K (equal parts, the remainder spread over the first ranges) of the extent of `m` along global axis `axis`
+Move3D stageOfMove(const Move3D& m, int axis, int k, int K);
 
 // canonical form used by the kernel layer: unit-extent dims dropped, mergeable dims fused, dims
 // ordered by source stride.  Returns the number of remaining dims (0..3).

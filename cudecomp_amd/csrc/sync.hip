@@ -6,6 +6,7 @@
 // (transport.cc: PeerContext): system-scope atomics on pinned host memory are coherent across GPUs and processes
 // by construction, whatever the caching policy of the data buffers.  Three 1-wave kernels:
 //
+//   (flag value = call number * kFlagScale + step, see below)
 //   epoch_begin_k   epoch += 1 (the call's number, kept in DEVICE memory so that a captured graph replays with fresh
 //                   epochs) and publish it in my `ready` flag: "everything before this call on my stream is done;
 //                   my receive area / output pencil may be written".
@@ -25,29 +26,32 @@ namespace {
 
 using u64 = unsigned long long;
 
+// A flag holds  call number * kFlagScale + step:  step 0 = "the call has begun" (ready flags), steps 1 .. kFlagScale-2 =
+// stages of a staged exchange that have completely landed, kFlagScale-1 = "everything of this call has landed".
 __global__ void epoch_begin_k(u64* epoch, u64* ready) {
   if (threadIdx.x == 0) {
     const u64 e = *epoch + 1;
     *epoch = e;
-    if (ready) __hip_atomic_store(ready, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ready) __hip_atomic_store(ready, e * kFlagScale, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
-__global__ void signal_k(const u64* epoch, const FlagList flags) {
+__global__ void signal_k(const u64* epoch, const FlagList flags, u64 step) {
   const int i = threadIdx.x;
-  if (i < flags.n) __hip_atomic_store(flags.f[i], *epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (i < flags.n) __hip_atomic_store(flags.f[i], *epoch * kFlagScale + step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void wait_k(const u64* epoch, const FlagList flags, u64* status, long long timeout_ticks) {
+__global__ void wait_k(const u64* epoch, const FlagList flags, u64* status, long long timeout_ticks, u64 step) {
   const int i = threadIdx.x;
   if (i < flags.n) {
-    const u64 e = *epoch;
+    const u64 call = *epoch;
+    const u64 e = call * kFlagScale + step;
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(flags.f[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
       __builtin_amdgcn_s_sleep(16);
       if (wall_clock64() - t0 > timeout_ticks) {
         // leave a trace for the host (checked at the next library call) and let the stream drain
-        __hip_atomic_store(status, (e << 8) | (u64)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(status, (call << 8) | (u64)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
     }
@@ -125,16 +129,16 @@ void launchEpochBegin(unsigned long long* epoch, unsigned long long* ready, hipS
   CD_CHECK_HIP(hipGetLastError());
 }
 
-void launchSignal(const unsigned long long* epoch, const FlagList& flags, hipStream_t stream) {
+void launchSignal(const unsigned long long* epoch, const FlagList& flags, hipStream_t stream, int step) {
   if (flags.n == 0) return;
-  signal_k<<<1, 64, 0, stream>>>(epoch, flags);
+  signal_k<<<1, 64, 0, stream>>>(epoch, flags, (u64)step);
   CD_CHECK_HIP(hipGetLastError());
 }
 
 void launchWait(const unsigned long long* epoch, const FlagList& flags, unsigned long long* status, double timeout_s,
-                hipStream_t stream) {
+                hipStream_t stream, int step) {
   if (flags.n == 0) return;
-  wait_k<<<1, 64, 0, stream>>>(epoch, flags, status, (long long)(timeout_s * 1e8));
+  wait_k<<<1, 64, 0, stream>>>(epoch, flags, status, (long long)(timeout_s * 1e8), (u64)step);
   CD_CHECK_HIP(hipGetLastError());
 }
 

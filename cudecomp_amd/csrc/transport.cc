@@ -463,7 +463,8 @@ class PeerContext {
     if (!board_ || slot < 0) return 0;
     uint64_t v = cell(slot, h_->rank).load(std::memory_order_relaxed);
     const u64* row = reinterpret_cast<const u64*>(board_ + flagRowOff(slot, h_->rank));
-    for (int i = 0; i < 1 + landed_n_; ++i) v = std::max<uint64_t>(v, reinterpret_cast<const std::atomic<uint64_t>*>(row + i)->load());
+    for (int i = 0; i < 1 + landed_n_; ++i)  // (flags hold call * kFlagScale + step: round up to whole calls)
+      v = std::max<uint64_t>(v, (reinterpret_cast<const std::atomic<uint64_t>*>(row + i)->load() + kFlagScale - 1) / kFlagScale);
     for (int par = 0; par < 2; ++par) v = std::max<uint64_t>(v, mail(slot, h_->rank, par).seq.load());
     return v;
   }
@@ -1010,7 +1011,7 @@ void peerReadyGate(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan
   const int P = ci.nranks;
   FlagList ready;
   for (int j = 1; j < P; ++j) ready.add(pc.dReady(ci.barrier_slot, ci.global_ranks[p.schedule_dst[j]]));
-  launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, stream);
+  launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, stream, kFlagBegun);
   CD_CHECK_HIP(hipEventRecord(pc.copyEvent(2 * P), stream));  // "go": receivers ready
 }
 
@@ -1063,7 +1064,7 @@ void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePl
     landed.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[m], h->rank));
     incoming.add(pc.dLanded(ci.barrier_slot, h->rank, ci.global_ranks[m]));
   }
-  launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, stream);  // every destination may be written
+  launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, stream, kFlagBegun);  // every destination may be written
 
   std::vector<Move3D> moves;
   std::vector<void*> dst_base;
@@ -1150,45 +1151,104 @@ void peerVerifyExchange(cudecompHandle_t h, cudecompCommInfo& ci, const Transpos
   (void)me;
 }
 
-// Per-peer pipeline of the one-sided transport (NVSHMEM_PL / MPI_P2P_PL enums): chunk by chunk
-//   pack(d) [caller, event per destination] -> copy to d over xGMI [one stream per peer] -> d unpacks it
-// A copy to d starts as soon as the receivers are ready (one wait on the caller's stream behind the first pack,
-// peerReadyGate) and d's chunk is packed, and the unpack of the chunk from s
-// is enqueued behind a wait for s's landed flag -- packs, the P-1 link transfers and unpacks overlap, all of it on
-// the device (counterpart of comm_routines.h:427-631 + transpose.h:470-513, 683-744).
-void peerPipelinedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
-                           void* const bufs[3], const ExchangeBuffers& b, int es, const PeerCall& call,
-                           hipStream_t stream) {
+// Staged pipeline of the one-sided transport (NVSHMEM_PL / MPI_P2P_PL enums).
+//
+// The reference pipelines PER PEER (comm_routines.h:427-631, transpose.h:470-513, 683-744): one peer's chunk is packed,
+// sent and unpacked after the other.  On a full xGMI mesh that is the wrong unit: every peer has a link of its own, so a
+// per-peer pipeline keeps one link busy at a time while the others wait for their turn, and each per-peer unpack launch
+// writes one slice of every destination row (a 2-KiB piece of every 8-KiB row leaves most DRAM channels idle:
+// 0.54-0.57 of the HBM peak, profiles/r02_local_phases.json).  Here the pipeline runs over STAGES instead: all chunks
+// are cut into K ranges along their slowest wire dim (contiguous sub-chunks in the send and receive areas), and stage k
+//   pack(k): one launch, all destinations            [caller's stream, event per stage]
+//   send(k): sub-chunk k to EVERY peer at once        [copy stream(s): all links busy in every stage] + landed = k
+//   unpack(k): one launch, all sources, whole rows   [caller's stream, behind a wait for stage k of every source]
+// overlaps pack(k+1) with send(k) and send(k+1) with unpack(k).  The receivers' "ready" is awaited once, on the
+// caller's stream behind the first pack; no stream ever parks a spinning kernel in front of work that could run.
+void peerStagedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
+                        void* const bufs[3], const ExchangeBuffers& b, int es, const PeerCall& call, hipStream_t stream) {
+  (void)gd;
   PeerContext& pc = peerOf(h, ci);
-  const int P = plan.nranks, me = plan.comm_rank;
-  hipEvent_t go = pc.copyEvent(2 * P);  // recorded by peerReadyGate after the first pack: every receiver is ready
+  const int P = plan.nranks, me = plan.comm_rank, ax = plan.stage_axis;
+  const int K = (int)std::max<i64>(1, std::min<i64>({(i64)h->pipeline_stages, plan.stage_limit, (i64)kFlagDone}));
+  auto stepOf = [&](int k) { return k == K - 1 ? kFlagDone : k + 1; };
+  // events: [0, P) last copy of each copy stream, 2P "go", then one "packed" event per stage
+  auto packedEvent = [&](int k) { return pc.copyEvent(2 * P + 2 + k); };
+  const bool cu = h->peer_copy_engine == 1;
+  const int ncopy = (P > 1) ? (cu ? 1 : P - 1) : 0;  // compute-unit copies: one launch feeds all links; SDMA: a stream per peer
+
+  FlagList ready, landed_all, incoming;
   for (int j = 1; j < P; ++j) {
-    const int d = plan.schedule_dst[j];
-    hipStream_t cs = pc.copyStream(j);
-    CD_CHECK_HIP(hipStreamWaitEvent(cs, gd->events[d], 0));  // chunk for d is packed
-    CD_CHECK_HIP(hipStreamWaitEvent(cs, go, 0));
-    peerCopy(h, call.remote_recv[d] + plan.remote_recv_off[d] * es, b.send + plan.send_off[d] * es, (size_t)plan.send_cnt[d] * es, cs);
-    FlagList landed;
-    landed.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[d], h->rank));
-    launchSignal(call.epoch, landed, cs);
-    CD_CHECK_HIP(hipEventRecord(pc.copyEvent(j), cs));
+    ready.add(pc.dReady(ci.barrier_slot, ci.global_ranks[plan.schedule_dst[j]]));
+    landed_all.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[plan.schedule_dst[j]], h->rank));
+    incoming.add(pc.dLanded(ci.barrier_slot, h->rank, ci.global_ranks[plan.schedule_src[j]]));
   }
-  for (int j = 0; j < P; ++j) {
-    const int s = (j == 0) ? me : plan.schedule_src[j];
-    if (j == 0) {
-      CD_CHECK_HIP(hipStreamWaitEvent(stream, gd->events[me], 0));
-      if (plan.send_cnt[me])
-        peerCopy(h, b.recv + plan.recv_off[me] * es, b.send + plan.send_off[me] * es, (size_t)plan.send_cnt[me] * es, stream,
-                 h->self_exchange ? -1 : 0);
-    } else {
-      FlagList incoming;
-      incoming.add(pc.dLanded(ci.barrier_slot, h->rank, ci.global_ranks[s]));
-      launchWait(call.epoch, incoming, pc.dStatus(), h->peer_timeout_s, stream);
+  hipEvent_t go = pc.copyEvent(2 * P);
+
+  std::vector<Move3D> moves;
+  for (int k = 0; k < K; ++k) {
+    // ---- pack stage k (all destinations, self included) on the caller's stream
+    if (!plan.pack.empty()) {
+      moves.clear();
+      for (const Move3D& m : plan.pack) moves.push_back(stageOfMove(m, ax, k, K));
+      launchMoves(moves.data(), (int)moves.size(), bufs, es, stream, &h->tuning);
     }
-    for (const Move3D& m : plan.unpack)
-      if (m.peer == s) launchMoves(&m, 1, bufs, es, stream, &h->tuning);
+    CD_CHECK_HIP(hipEventRecord(packedEvent(k), stream));
+    if (k == 0) {  // receivers ready? (once, behind the first pack)
+      launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, stream, kFlagBegun);
+      CD_CHECK_HIP(hipEventRecord(go, stream));
+    }
+    // ---- send stage k to every peer
+    if (cu && P > 1) {
+      hipStream_t cs = pc.copyStream(1);
+      CD_CHECK_HIP(hipStreamWaitEvent(cs, packedEvent(k), 0));
+      if (k == 0) CD_CHECK_HIP(hipStreamWaitEvent(cs, go, 0));
+      moves.clear();
+      std::vector<void*> dst_base;
+      for (int j = 1; j < P; ++j) {
+        const int d = plan.schedule_dst[j];
+        const i64 n = plan.send_n[d], per = plan.send_cnt[d] / n, lo = n * k / K, hi = n * (k + 1) / K;
+        if (hi == lo) continue;
+        Move3D r;
+        r.src_buf = plan.send_buf;
+        r.src_off = plan.send_base + plan.send_off[d] + lo * per;
+        r.dst_off = plan.remote_recv_off[d] + lo * per;
+        r.extent[0] = (hi - lo) * per;
+        r.ss[0] = r.ds[0] = 1;
+        r.peer = d;
+        moves.push_back(r);
+        dst_base.push_back(call.remote_recv[d]);
+      }
+      if (!moves.empty()) launchMoves(moves.data(), (int)moves.size(), bufs, es, cs, &h->tuning, nullptr, dst_base.data());
+      launchSignal(call.epoch, landed_all, cs, stepOf(k));
+      if (k == K - 1) CD_CHECK_HIP(hipEventRecord(pc.copyEvent(1), cs));
+    } else {
+      for (int j = 1; j < P; ++j) {
+        const int d = plan.schedule_dst[j];
+        hipStream_t cs = pc.copyStream(j);
+        CD_CHECK_HIP(hipStreamWaitEvent(cs, packedEvent(k), 0));
+        if (k == 0) CD_CHECK_HIP(hipStreamWaitEvent(cs, go, 0));
+        const i64 n = plan.send_n[d], per = plan.send_cnt[d] / n, lo = n * k / K, hi = n * (k + 1) / K;
+        peerCopy(h, call.remote_recv[d] + (plan.remote_recv_off[d] + lo * per) * es, b.send + (plan.send_off[d] + lo * per) * es,
+                 (size_t)((hi - lo) * per) * es, cs);
+        FlagList landed;
+        landed.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[d], h->rank));
+        launchSignal(call.epoch, landed, cs, stepOf(k));
+        if (k == K - 1) CD_CHECK_HIP(hipEventRecord(pc.copyEvent(j), cs));
+      }
+    }
   }
-  for (int j = 1; j < P; ++j) CD_CHECK_HIP(hipStreamWaitEvent(stream, pc.copyEvent(j), 0));  // send area reusable
+  // my own chunk: a local copy (reference: comm_routines.h:405-410), or through the engine under test
+  if (plan.send_cnt[me])
+    peerCopy(h, b.recv + plan.recv_off[me] * es, b.send + plan.send_off[me] * es, (size_t)plan.send_cnt[me] * es, stream,
+             h->self_exchange ? -1 : 0);
+  // ---- unpack stage by stage: every source's sub-chunk k has landed -> one launch that writes whole rows
+  for (int k = 0; k < K; ++k) {
+    launchWait(call.epoch, incoming, pc.dStatus(), h->peer_timeout_s, stream, stepOf(k));
+    moves.clear();
+    for (const Move3D& m : plan.unpack) moves.push_back(stageOfMove(m, ax, k, K));
+    if (!moves.empty()) launchMoves(moves.data(), (int)moves.size(), bufs, es, stream, &h->tuning);
+  }
+  for (int j = 1; j <= ncopy; ++j) CD_CHECK_HIP(hipStreamWaitEvent(stream, pc.copyEvent(j), 0));  // send area reusable
 }
 
 void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t, cudecompCommInfo& ci, const TransposePlan& plan,
@@ -1295,7 +1355,7 @@ hipEvent_t haloReadyGate(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloEx
   FlagList both;
   for (int i = 0; i < 2; ++i)
     if (x.neighbor[i] != -1 && (i == 0 || x.neighbor[1] != x.neighbor[0])) both.add(pc.dReady(ci.barrier_slot, x.neighbor[i]));
-  launchWait(call.epoch, both, pc.dStatus(), h->peer_timeout_s, stream);
+  launchWait(call.epoch, both, pc.dStatus(), h->peer_timeout_s, stream, kFlagBegun);
   hipEvent_t ready_ev = pc.copyEvent(2 * ci.nranks + 1);
   CD_CHECK_HIP(hipEventRecord(ready_ev, stream));
   return ready_ev;

@@ -83,14 +83,11 @@ void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInf
 void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, void* const bufs[3], int es,
                      const PeerCall& call, hipStream_t stream);
 
-// Per-peer pipeline of the one-sided transport.  Preconditions: gd->events[d] was recorded on `stream` after the pack
-// kernel of destination d, and peerReadyGate() was enqueued on `stream` (after the first pack).  Launches the unpack
-// moves itself.
-void peerReadyGate(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, const PeerCall& call, hipStream_t stream);
+// Staged pipeline of the one-sided transport (pack / send / unpack overlapped stage by stage, all peers in every
+// stage).  Runs the plan's pack and unpack moves itself.
 bool peerPipelineAvailable(cudecompHandle_t h, const cudecompCommInfo& ci);
-void peerPipelinedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
-                           void* const bufs[3], const ExchangeBuffers& b, int es, const PeerCall& call,
-                           hipStream_t stream);
+void peerStagedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommInfo& ci, const TransposePlan& plan,
+                        void* const bufs[3], const ExchangeBuffers& b, int es, const PeerCall& call, hipStream_t stream);
 
 // debugging aid (CUDECOMP_DEBUG_VERIFY_EXCHANGE=1): host-synchronous check of what a one-sided exchange delivered
 void peerVerifyExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& plan, const ExchangeBuffers& b, int es,

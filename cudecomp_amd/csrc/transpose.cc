@@ -288,7 +288,16 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
     return;
   }
 
-  // Per-peer pipeline: pack chunk by chunk (an event per destination), then walk the pairwise schedule:
+  if (one_sided) {
+    // staged pipeline: pack / send / unpack overlap stage by stage with all peers in every stage (transport.cc)
+    gd->path_count[PATH_PEER_PIPELINED]++;
+    perfMark(pev, 1, stream);
+    peerStagedExchange(h, gd, ci, plan, bufs, xb, es, call, stream);
+    perfMark(pev, 2, stream);
+    perfMark(pev, 3, stream);
+    return;
+  }
+  // Per-peer pipeline (RCCL / MPI): pack chunk by chunk (an event per destination), then walk the pairwise schedule:
   // exchange with one peer on the side stream while the previous peer's chunk is being unpacked.
   const int P = plan.nranks;
   if ((int)gd->events.size() < P) {
@@ -303,7 +312,7 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
     // event-record NODE hanging off it, so the side stream can wait on the per-peer events after the launch --
     // and replayed as ONE graph launch on later calls with the same buffers.
     hipGraphExec_t exec = nullptr;
-    if (h->graphs_enable && !gd->graphs_failed && plan.pack.size() > 1 && !in_capture && !one_sided) {
+    if (h->graphs_enable && !gd->graphs_failed && plan.pack.size() > 1 && !in_capture) {
       const cudecompGridDesc::PackGraphKey gkey{key, input, output, work, es};
       auto git = gd->pack_graphs.find(gkey);
       if (git != gd->pack_graphs.end()) {
@@ -317,28 +326,13 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
       CD_CHECK_HIP(hipGraphLaunch(exec, stream));
       gd->graph_launches++;
     } else {
-      bool gated = !one_sided;
       for (const Move3D& m : plan.pack) {
         launchMoves(&m, 1, bufs, es, stream, &h->tuning);
         CD_CHECK_HIP(hipEventRecord(gd->events[m.peer], stream));
-        if (!gated) {  // the receivers' "ready" is awaited once, behind the first pack (transport.cc: peerReadyGate)
-          peerReadyGate(h, ci, plan, call, stream);
-          gated = true;
-        }
       }
-      if (!gated) peerReadyGate(h, ci, plan, call, stream);
     }
   } else {
     for (int d = 0; d < P; ++d) CD_CHECK_HIP(hipEventRecord(gd->events[d], stream));
-    if (one_sided) peerReadyGate(h, ci, plan, call, stream);
-  }
-  if (one_sided) {
-    // packs, link transfers and unpacks overlap chunk by chunk, ordered by the pairwise flags on the device
-    gd->path_count[PATH_PEER_PIPELINED]++;
-    peerPipelinedExchange(h, gd, ci, plan, bufs, xb, es, call, stream);
-    perfMark(pev, 2, stream);
-    perfMark(pev, 3, stream);
-    return;
   }
   gd->path_count[xpath]++;
   for (int j = 0; j < P; ++j) {

@@ -46,6 +46,13 @@ typedef struct {
    * the peer's buffer); no receive area, no unpack.  n_direct = 0: the plan has no such form. */
   int32_t n_direct, reserved2;
   cudecompExtMove_t direct[CUDECOMP_EXT_MAX_MEMBERS];
+  /* staged exchange of the one-sided pipelined transports: every chunk is cut into K <= stage_limit ranges along the
+   * global axis stage_axis (its slowest wire dim): range k of the chunk for member d is elements
+   * [send_n[d]*k/K, send_n[d]*(k+1)/K) * (send_cnt[d]/send_n[d]) of that chunk -- contiguous -- and the same range of
+   * extent[stage_axis] of its pack move; likewise recv_n / recv_cnt / unpack on the receiving side */
+  int32_t stage_axis, reserved3;
+  int64_t stage_limit;
+  int64_t send_n[CUDECOMP_EXT_MAX_MEMBERS], recv_n[CUDECOMP_EXT_MAX_MEMBERS];
 } cudecompExtTransposePlan_t;
 
 typedef struct {
@@ -115,6 +122,11 @@ typedef struct {
 } cudecompExtTransposeTimings_t;
 cudecompResult_t cudecompExtGetTransposeTimings(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t op,
                                                 cudecompExtTransposeTimings_t* timings);
+/* The same for cudecompUpdateHalos{X,Y,Z} (axis 0..2) along `dim`: pack / exchange / unpack of the plain sequence
+ * (CUDECOMP_DISABLE_HALO_OVERLAP=1); the overlapped sequence reports the whole update as exchange time.  pencil_bytes
+ * holds the bytes this rank put on the wire per update. */
+cudecompResult_t cudecompExtGetHaloTimings(cudecompHandle_t handle, cudecompGridDesc_t grid_desc, int32_t axis, int32_t dim,
+                                           cudecompExtTransposeTimings_t* timings);
 
 /* Peer-transport self test (collective): every rank writes tagged 4 KiB blocks at the start, middle, end and
  * every GiB boundary of the NEXT rank's copy of `buffer` (from cudecompMalloc, `bytes` long) and verifies what the

@@ -73,7 +73,7 @@ def run_config(name, gdims, pdims, es, layout, pipelined):
     del pen, work
     torch.cuda.empty_cache()
     return {"config": name, "gdims": list(gdims), "pdims": list(pdims), "element_bytes": es, "layout": layout,
-            "launch_form": "per peer (pipelined)" if pipelined else "one batch per phase", "ops": ops,
+            "launch_form": "per stage, all peers (one-sided pipelined, %s stages)" % os.environ.get("CUDECOMP_PIPELINE_STAGES", "4") if pipelined else "one batch per phase", "ops": ops,
             "cycle": {"local_ms": round(tot_local, 3), "link_ms_at_nominal": round(tot_link, 3),
                       "serial_ms": round(tot_local + tot_link, 3), "overlapped_floor_ms": round(max(tot_local, tot_link), 3)}}
 

@@ -698,3 +698,41 @@ def pool_behaviour(rank, nranks, args):
         failures += r["failures"]
     out["failures"] = failures
     return out
+
+
+def halo_timed(rank, nranks, args):
+    """cudecompUpdateHalos{X,Y,Z} timing per pencil axis and dim on a multi-rank grid (BASELINE config 5 when called with
+    its sizes): K timed updates per dim bracketed by device events, and the library's own per-phase samples (pack /
+    exchange / unpack; needs CUDECOMP_ENABLE_PERFORMANCE_REPORT=1 in the environment)."""
+    h, gd, g = _setup(rank, nranks, args)
+    halo, periods = args["halo"], args["periods"]
+    es = 8
+    out = {}
+    for axis in args.get("axes", [0, 1, 2]):
+        p = cd.cudecompGetPencilInfo(h, gd, axis, halo)
+        data = torch.zeros(p.size, dtype=torch.float64, device="cuda")
+        wsz = max(cd.cudecompGetHaloWorkspaceSize(h, gd, axis, halo), 1)
+        work = cd.cudecompMalloc(h, gd, wsz * es)
+        st = G.stream_ptr()
+        rec = {"pencil_shape": list(p.shape), "workspace_MiB": round(wsz * es / 2**20, 1)}
+        for dim in range(3):
+            for _ in range(args.get("warmup", 3)):
+                cd.cudecompUpdateHalos(axis, h, gd, data.data_ptr(), work, cd.DOUBLE, halo, periods, dim, None, st)
+            torch.cuda.synchronize()
+            reps = args.get("reps", 10)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                cd.cudecompUpdateHalos(axis, h, gd, data.data_ptr(), work, cd.DOUBLE, halo, periods, dim, None, st)
+            e1.record()
+            torch.cuda.synchronize()
+            t = cd.cudecompExtGetHaloTimings(h, gd, axis, dim)
+            rec["dim%d" % dim] = {"ms": round(e0.elapsed_time(e1) / reps, 4), "pack_ms": round(t["pack_ms"], 4),
+                                  "exchange_ms": round(t["exchange_ms"], 4), "unpack_ms": round(t["unpack_ms"], 4),
+                                  "samples": t["samples"], "wire_MiB": round(t["pencil_bytes"] / 2**20, 2)}
+        out["XYZ"[axis]] = rec
+        cd.cudecompFree(h, gd, work)
+        del data
+        torch.cuda.empty_cache()
+    cd.cudecompGridDescDestroy(h, gd)
+    return out

@@ -45,3 +45,16 @@ def test_poisson_example(nranks, args):
     logs = run_binary_ranks(nranks, [os.path.join(ROOT, "examples", "cc", "poisson")] + args)
     recs = [json.loads(line) for text in logs for line in text.splitlines() if line.startswith("{")]
     assert len(recs) == nranks and all(r["ok"] and r["max_abs_err"] < 1e-11 for r in recs), recs
+
+
+@pytest.mark.parametrize("backend,name", [(6, "nvshmem"), (8, "nvshmem_sm")])
+def test_config4_fft_full_size_on_2x4(backend, name):
+    """BASELINE config 4 on ITS grid: 1024^3 complex<fp32>, 2 x 4 pencils (8 ranks sharing the GPU), hipFFT lines +
+    the library's transposes, forward + inverse residual within the reference's tolerance (benchmark/benchmark.cu:23-27,
+    489-611: max-abs round-trip error <= 5e-4 for complex<float>), plus the plane-wave spectrum check on the distributed
+    Z pencils.  Every rank holds 1 GiB of data + 2 GiB of workspace."""
+    rec, ranks = run_fft3d.run(8, ["--gx", "1024", "--gy", "1024", "--gz", "1024", "--pr", "2", "--pc", "4", "--backend",
+                                   str(backend), "--warmup", "1", "--trials", "2"], timeout=900)
+    assert rec["ok"], rec
+    assert rec["pdims"] == [2, 4]
+    assert rec["roundtrip_max_abs_err"] <= 5e-4, rec

@@ -130,6 +130,102 @@ def test_transpose_cycle_returns_the_input(d, inplace, symmetric):
         simulate_transpose(d, op, zero, zero, inplace, False, symmetric, 0)
 
 
+def _stage_of(m, axis, k, K):
+    """python twin of csrc/plan.cc stageOfMove: range k of K of the move's extent along global axis `axis`"""
+    r = cd.ExtMove()
+    C_fields = ("src_buf", "dst_buf", "src_off", "dst_off", "peer", "reserved")
+    for f in C_fields:
+        setattr(r, f, getattr(m, f))
+    n = m.extent[axis]
+    lo, hi = n * k // K, n * (k + 1) // K
+    for i in range(3):
+        r.extent[i], r.ss[i], r.ds[i] = m.extent[i], m.ss[i], m.ds[i]
+    r.extent[axis] = hi - lo
+    r.src_off = m.src_off + lo * m.ss[axis]
+    r.dst_off = m.dst_off + lo * m.ds[axis]
+    return r
+
+
+def simulate_staged_transpose(d, op, halos, pads, inplace, stages, npergroup):
+    """The staged pipeline of the one-sided pipelined transports (csrc/transport.cc peerStagedExchange) on host arrays:
+    stage by stage, pack the stage's range of every chunk, deliver ONLY the matching contiguous sub-chunks, unpack the
+    stage's range from every source.  The receive areas start poisoned, so an unpack stage that touched a range
+    belonging to a later stage would spoil the output."""
+    spec, g = _grids(d)
+    n = g.nranks
+    ai, ao = orc.OP_AXES[op]
+    pa = [g.pencil_info(r, ai, halos[0], pads[0]) for r in range(n)]
+    pb = [g.pencil_info(r, ao, halos[1], pads[1]) for r in range(n)]
+    wsz = g.transpose_workspace_size()
+    plans = [cd.cudecompExtPlanTranspose(spec, r, op, halos[0], halos[1], pads[0], pads[1], inplace, True, True, npergroup)
+             for r in range(n)]
+    bufs = []
+    for r in range(n):
+        nel = max(pa[r].size, pb[r].size)
+        a = np.full(nel, -7, dtype=DT)
+        a[:pa[r].size] = g.fill_pencil(pa[r], KIND)
+        b = a if inplace else np.full(nel, -9, dtype=DT)
+        bufs.append([a, b, np.full(wsz, -11, dtype=DT)])
+    exchanging = [p for p in plans if not p.noop and p.exchange]
+    if not exchanging:
+        return simulate_transpose(d, op, halos, pads, inplace, True, True, npergroup)
+    by_comm = {}
+    for r, p in enumerate(plans):  # every member of one communicator must arrive at the same stage axis and limit
+        if p.exchange:
+            key = tuple(p.member_global_rank[i] for i in range(p.nranks))
+            by_comm.setdefault(key, set()).add((p.stage_axis, p.stage_limit))
+    assert all(len(v) == 1 for v in by_comm.values()), by_comm
+    K_of = [max(1, min(stages, p.stage_limit)) if (not p.noop and p.exchange) else 1 for p in plans]
+    Kmax = max(K_of)
+    # the executor issues ALL pack stages before the first unpack stage on the caller's stream (an in-place unpack may
+    # overwrite input that a later pack stage still needs); transfers of stage k may start as soon as pack k is done
+    flights = [[] for _ in range(Kmax)]
+    for k in range(Kmax):
+        for r in range(n):
+            p, K = plans[r], K_of[r]
+            if p.noop or not p.exchange or k >= K:
+                continue
+            moves = (cd.ExtMove * max(p.n_pack, 1))(*[_stage_of(p.pack[i], p.stage_axis, k, K) for i in range(p.n_pack)])
+            run_moves(moves, p.n_pack, bufs[r])
+            for di in range(p.nranks):
+                gr = p.member_global_rank[di]
+                q = plans[gr]
+                assert K_of[gr] == K, "members of one communicator disagree on the number of stages"
+                nn = p.send_n[di]
+                assert nn == q.recv_n[p.comm_rank] and p.send_cnt[di] % nn == 0
+                per = p.send_cnt[di] // nn
+                lo, hi = nn * k // K, nn * (k + 1) // K
+                so = p.send_base + p.send_off[di] + lo * per
+                flights[k].append((gr, q.recv_buf, q.recv_base + q.recv_off[p.comm_rank] + lo * per,
+                                   bufs[r][p.send_buf][so:so + (hi - lo) * per].copy()))
+    for k in range(Kmax):
+        for gr, buf, off, data in flights[k]:
+            bufs[gr][buf][off:off + data.size] = data
+        for r in range(n):
+            p, K = plans[r], K_of[r]
+            if p.noop or not p.exchange or k >= K:
+                continue
+            moves = (cd.ExtMove * max(p.n_unpack, 1))(*[_stage_of(p.unpack[i], p.stage_axis, k, K) for i in range(p.n_unpack)])
+            run_moves(moves, p.n_unpack, bufs[r])
+    for r in range(n):
+        got = np.ascontiguousarray(bufs[r][1][:pb[r].size])
+        exp = g.fill_pencil(pb[r], KIND)
+        bad = orc.compare_pencil(pb[r], KIND, exp, got, True)
+        assert bad == 0, "rank %d: output pencil wrong at element %d (staged, %d stages)" % (r, bad - 1, stages)
+
+
+@settings(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck))
+@given(d=decompositions(), op=st.sampled_from(cd.OPS), in_halo=small3, out_halo=small3, in_pad=small3, out_pad=small3,
+       inplace=st.booleans(), stages=st.integers(1, 6), grouped=st.booleans())
+def test_staged_exchange_random_decompositions(d, op, in_halo, out_halo, in_pad, out_pad, inplace, stages, grouped):
+    P = d["pdims"][0] if op in ("XToY", "YToX") else d["pdims"][1]
+    npergroup = 0
+    if grouped and P > 1:
+        divisors = [k for k in range(1, P + 1) if P % k == 0]
+        npergroup = divisors[len(divisors) // 2]
+    simulate_staged_transpose(d, op, (in_halo, out_halo), (in_pad, out_pad), inplace, stages, npergroup)
+
+
 def simulate_direct_put(d, op, halos, pads, npergroup):
     """The direct-to-destination form of the one-sided plans: every rank's `direct` moves read its own input pencil
     and write the owners' OUTPUT pencils in their final layout -- no workspace, no unpack.  Destinations written by
