@@ -126,7 +126,7 @@ EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecom
                "cudecompExtGetTransposeTimings", "cudecompExtGetHaloTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
                "cudecompExtPlanTranspose", "cudecompExtPlanHalo", "cudecompExtPencilInfo", "cudecompExtShiftedRank",
                "cudecompExtWorkspaceSizes", "cudecompExtGetLinkInfo", "cudecompExtLastKernelName",
-               "cudecompExtRunLocalPhases"]
+               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -202,6 +202,7 @@ def lib():
         L.cudecompExtPlanHalo.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, C.POINTER(C.c_bool), i32, pi32, i32,
                                           C.POINTER(ExtHaloPlan)]
         L.cudecompExtGetLinkInfo.argtypes = [vp, C.POINTER(ExtLinkInfo)]
+        L.cudecompExtEstimateCycleMs.argtypes = [vp, C.POINTER(ExtGridSpec), i32, i32, i32, i32, C.POINTER(C.c_double)]
         L.cudecompExtRunLocalPhases.argtypes = [C.POINTER(ExtGridSpec), i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
         L.cudecompExtLastKernelName.argtypes = []
         L.cudecompExtLastKernelName.restype = C.c_char_p
@@ -430,6 +431,14 @@ def cudecompExtGetCounters(handle, gd):
 
 def cudecompExtLastKernelName():
     return lib().cudecompExtLastKernelName().decode()
+
+
+def cudecompExtEstimateCycleMs(handle, grid_spec, es, backend, library_buffers=False, inplace=False):
+    """the autotuner's analytic prior for one (grid, backend) candidate, in ms per X->Y->Z->Y->X cycle"""
+    ms = C.c_double(0)
+    _check(lib().cudecompExtEstimateCycleMs(handle, C.byref(grid_spec), es, backend, int(library_buffers), int(inplace),
+                                            C.byref(ms)), "cudecompExtEstimateCycleMs")
+    return ms.value
 
 
 def cudecompExtGetLinkInfo(handle):

@@ -214,6 +214,11 @@ bool unevenGrid(const cudecompGridDescConfig_t& c) {
          c.gdims_dist[2] % c.pdims[1] != 0;
 }
 
+bool envIsOneLocal(const char* name) {
+  const char* v = std::getenv(name);
+  return v && std::strtol(v, nullptr, 10) == 1;
+}
+
 double envDouble(const char* name, double dflt) {
   const char* v = std::getenv(name);
   return v ? std::strtod(v, nullptr) : dflt;
@@ -228,12 +233,15 @@ double envDouble(const char* name, double dflt) {
 }  // namespace
 
 // Analytic cost of one X->Y->Z->Y->X cycle on an xGMI full mesh (one dedicated link per GPU pair inside a
-// node), in ms.  Per transpose: local passes stream the pencil through HBM, the exchange sends one chunk
-// per peer and all chunks travel concurrently on their own links, so its time is ONE chunk over ONE link
-// (independent of the communicator size), or the whole off-node volume over the NIC share when the
-// communicator leaves the node.  Used to order candidates (most promising first, which makes
-// skip_threshold effective) -- the winner is always decided by measurement.
-double estimateTransposeCycleMs(cudecompHandle_t h, const GridShape& g, int es) {
+// node), in ms, for ONE (grid, backend) candidate.  Per transpose: every local phase THE PLAN EXECUTES streams the
+// pencil through HBM once (pack and unpack are elided where the layout allows, transpose.h:395-402; the fused put of
+// NVSHMEM_SM packs while it sends, and with pencils in library memory writes the destination pencils directly: one
+// pass in all); the exchange sends one chunk per peer and all chunks travel concurrently on their own links, so its
+// time is ONE chunk over ONE link (independent of the communicator size), or the whole off-node volume over the NIC
+// share when the communicator leaves the node.  Staged / pipelined transports overlap the two.  Used to order
+// candidates (most promising first, which makes skip_threshold effective) -- the winner is decided by measurement.
+double estimateTransposeCycleMs(cudecompHandle_t h, const GridShape& g, int es, cudecompTransposeCommBackend_t backend,
+                                bool library_buffers, const bool inplace[4]) {
   const double hbm = envDouble("CUDECOMP_MODEL_HBM_GBPS", 6290.0) * 1e9;
   // ONE direction of ONE xGMI link: the rate measured when the one-sided transport came up (ranks on different GPUs),
   // else the nominal 76.8 GB/s (a link is quoted at 153.6 GB/s counting both directions)
@@ -243,18 +251,41 @@ double estimateTransposeCycleMs(cudecompHandle_t h, const GridShape& g, int es) 
   const double link = envDouble("CUDECOMP_MODEL_XGMI_LINK_GBPS", link_gbps) * 1e9;
   const double nic = envDouble("CUDECOMP_MODEL_NIC_GBPS", 50.0) * 1e9;
   const double pencil = (double)maxPencilElements(g, 0) * es;
+  TransportTraits traits;
+  traits.pipelined = transposeBackendIsPipelined(backend);
+  traits.symmetric_recv = usesPeerTransport(h, backend);
+  traits.self_exchange = h->self_exchange;
+  const bool fused = backend == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_SM;
+  const int32_t zero[3] = {0, 0, 0};
   double total = 0;
   for (int op = 0; op < 4; ++op) {
     const int P = (op == 0 || op == 3) ? g.pdims[0] : g.pdims[1];
-    double local = 2.0 * pencil / hbm;  // at least one pass (read + write)
+    const bool ip = inplace && inplace[op];
+    int passes = 1;
+    bool staged = false;
+    try {
+      const TransposePlan p = buildTransposePlan(g, h->rank, (TransposeOp)op, zero, zero, zero, zero, ip, traits, std::max(P, 1));
+      if (p.noop) continue;
+      if (p.exchange) {
+        const bool direct = fused && library_buffers && h->direct_put && !ip && !p.direct.empty();
+        passes = direct ? 1 : ((fused || !p.pack.empty()) ? 1 : 0) + (p.unpack.empty() ? 0 : 1);
+        staged = traits.pipelined && traits.symmetric_recv;
+      } else {
+        passes = (int)(!p.pack.empty()) + (int)(!p.unpack.empty());
+      }
+    } catch (const Error&) {
+      passes = 2;  // (an unsupported candidate is rejected elsewhere; keep the ordering total)
+    }
+    const double local = passes * 2.0 * pencil / hbm;
     double comm = 0;
     if (P > 1) {
-      local *= 2;  // pack and unpack
       const double chunk = pencil / P;
       const bool on_node = P <= h->local_nranks;
       comm = on_node ? chunk / link : chunk * (P - 1) / nic;
     }
-    total += local + comm;
+    if (fused && P > 1) total += std::max(comm, 2.0 * pencil / hbm) + (passes > 1 ? 2.0 * pencil / hbm : 0.0);  // the put IS the pack
+    else if (staged) total += std::max(local, comm) + std::min(local, comm) / std::max(1, h->pipeline_stages);
+    else total += local + comm;
   }
   return total * 1e3;
 }
@@ -306,7 +337,12 @@ void autotuneTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecomp
         s.gdims_dist[i] = gd->config.gdims_dist[i];
       }
       s.pdims = pd;
-      ranked.push_back({estimateTransposeCycleMs(h, s, (int)es), pd});
+      // (grids are ordered by their best backend's estimate)
+      double best_est = 1e300;
+      for (auto b : backends)
+        best_est = std::min(best_est, estimateTransposeCycleMs(h, s, (int)es, b, envIsOneLocal("CUDECOMP_AUTOTUNE_LIBRARY_BUFFERS"),
+                                                               opt->transpose_use_inplace_buffers));
+      ranked.push_back({best_est, pd});
     }
     std::stable_sort(ranked.begin(), ranked.end(), [](auto& a, auto& b) { return a.first < b.first; });
     for (size_t i = 0; i < grids.size(); ++i) grids[i] = ranked[i].second;
@@ -459,7 +495,8 @@ void autotuneTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecomp
             printf("CUDECOMP:\tTranspose%s time min/max/avg/std [ms]: %f/%f/%f/%f%s\n", names[i], so[i].min, so[i].max,
                    so[i].avg, so[i].std, opt->transpose_op_weights[i] == 0.0 ? " (skipped)" : "");
           if (std::getenv("CUDECOMP_AUTOTUNE_PRINT_MODEL"))
-            printf("CUDECOMP:\txGMI-mesh model estimate [ms]: %f\n", estimateTransposeCycleMs(h, gd->shape, (int)es));
+            printf("CUDECOMP:\txGMI-mesh model estimate [ms]: %f\n",
+                   estimateTransposeCycleMs(h, gd->shape, (int)es, backend, library_data, opt->transpose_use_inplace_buffers));
         }
         fflush(stdout);
       }

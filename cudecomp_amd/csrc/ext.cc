@@ -338,6 +338,24 @@ cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDes
 
 const char* cudecompExtLastKernelName(void) { return lastKernelName(); }
 
+cudecompResult_t cudecompExtEstimateCycleMs(cudecompHandle_t handle, const cudecompExtGridSpec_t* grid, int32_t es,
+                                            int32_t backend, int32_t library_buffers, int32_t inplace, double* ms) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    if (!grid || !ms) CD_INVALID_USAGE("null argument");
+    if (es != 4 && es != 8 && es != 16) CD_INVALID_USAGE("element size must be 4, 8 or 16");
+    if (backend < 1 || backend > 8) CD_INVALID_USAGE("backend out of range");
+    const GridShape g = shapeFromSpec(grid);
+    const bool ip[4] = {inplace != 0, inplace != 0, inplace != 0, inplace != 0};
+    *ms = estimateTransposeCycleMs(handle, g, es, (cudecompTransposeCommBackend_t)backend, library_buffers != 0, ip);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
 cudecompResult_t cudecompExtGetLinkInfo(cudecompHandle_t handle, cudecompExtLinkInfo_t* out) {
   try {
     if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");

@@ -243,6 +243,9 @@ void perfDestroy(cudecompGridDesc_t gd);
 // autotune.cc
 void autotuneTranspose(cudecompHandle_t handle, cudecompGridDesc_t gd, const cudecompGridDescAutotuneOptions_t* opt,
                        bool autotune_backend, bool autotune_pdims);
+// analytic cost (ms) of one X->Y->Z->Y->X cycle for a (grid, backend) candidate on an xGMI full mesh
+double estimateTransposeCycleMs(cudecompHandle_t h, const GridShape& g, int es, cudecompTransposeCommBackend_t backend,
+                                bool library_buffers, const bool inplace[4]);
 void autotuneHalo(cudecompHandle_t handle, cudecompGridDesc_t gd, const cudecompGridDescAutotuneOptions_t* opt,
                   bool autotune_backend, bool autotune_pdims);
 std::vector<cudecompTransposeCommBackend_t> transposeBackendCandidates(const cudecompGridDescAutotuneOptions_t* opt);

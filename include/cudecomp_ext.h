@@ -163,6 +163,13 @@ cudecompResult_t cudecompExtGetLinkInfo(cudecompHandle_t handle, cudecompExtLink
  * "transpose_kernel<8,2,64,64,2,true>"); "" before the first launch.  The string is owned by the library. */
 const char* cudecompExtLastKernelName(void);
 
+/* The autotuner's analytic prior (csrc/autotune.cc estimateTransposeCycleMs): cost in ms of one X->Y->Z->Y->X cycle of
+ * `es`-byte elements for the grid and transpose backend given, from the phases the plan really executes, the HBM rate
+ * and one chunk per link (CUDECOMP_MODEL_HBM_GBPS / _XGMI_LINK_GBPS / _NIC_GBPS override the rates).  library_buffers:
+ * pencils live in cudecompMalloc memory (NVSHMEM_SM then writes the destination pencils directly). */
+cudecompResult_t cudecompExtEstimateCycleMs(cudecompHandle_t handle, const cudecompExtGridSpec_t* grid, int32_t es,
+                                            int32_t backend, int32_t library_buffers, int32_t inplace, double* ms);
+
 /* Run one block move on the GPU (src/dst are device pointers, strides in elements of es bytes).
  * force_generic is a bit mask: 1 selects the element-wise fallback kernel, 2 forces the streaming
  * (non-temporal) variants that are normally used only for moves of 32 MiB and more, 4 selects the window variant of

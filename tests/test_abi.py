@@ -286,3 +286,31 @@ def test_multiple_live_handles_four_ranks(golden_dir):
     # and the two rank orders really differ on the off-diagonal ranks
     assert by_rank[1]["pencil_row_major"] != by_rank[1]["pencil_col_major"]
     assert by_rank[1]["pencil_col_major"] == by_rank[2]["pencil_row_major"]
+
+
+def test_autotune_prior_follows_the_plans(handle, monkeypatch):
+    """The analytic prior that orders the autotuner's candidates (csrc/autotune.cc estimateTransposeCycleMs; reference
+    src/autotune.cc:94-106, 675 only orders grids by factor) charges the phases the plan EXECUTES and one chunk per
+    link: on a full mesh slab grids beat 2 x 4, the fused put with library buffers (direct to destination: one pass) beats
+    the staged transports, the staged pipeline beats the unpipelined exchange, and elided phases are not charged."""
+    monkeypatch.setenv("CUDECOMP_MODEL_XGMI_LINK_GBPS", "76.8")
+    monkeypatch.setenv("CUDECOMP_MODEL_HBM_GBPS", "6000")
+    contiguous = [(0, 1, 2), (1, 2, 0), (2, 0, 1)]
+    default = [(0, 1, 2)] * 3
+
+    def est(pdims, backend, orders=contiguous, lib=False, inplace=False):
+        spec = cd.make_grid_spec((1024, 1024, 1024), pdims, orders)
+        # a one-rank handle: the model treats communicators larger than the node as off-node, so use the NIC = link rate
+        return cd.cudecompExtEstimateCycleMs(handle, spec, 8, backend, lib, inplace)
+
+    monkeypatch.setenv("CUDECOMP_MODEL_NIC_GBPS", str(76.8 * 7))  # 7 links' worth: what a full mesh gives one GPU
+    b = cd.TRANSPOSE_COMM_NVSHMEM
+    assert est((1, 8), b) < est((2, 4), b) and est((8, 1), b) < est((4, 2), b)
+    assert est((1, 8), cd.TRANSPOSE_COMM_NVSHMEM_SM, lib=True) < est((1, 8), cd.TRANSPOSE_COMM_NVSHMEM_SM, lib=False)
+    assert est((1, 8), cd.TRANSPOSE_COMM_NVSHMEM_SM, lib=True) < est((1, 8), cd.TRANSPOSE_COMM_NVSHMEM)
+    assert est((1, 8), cd.TRANSPOSE_COMM_NVSHMEM_PL) < est((1, 8), cd.TRANSPOSE_COMM_NVSHMEM)
+    # default layout on 1 x 8: Y->Z needs no unpack and Z->Y no pack (transpose.h:395-402) with a two-sided transport
+    assert est((1, 8), cd.TRANSPOSE_COMM_NCCL, orders=default) < est((1, 8), cd.TRANSPOSE_COMM_NCCL, orders=contiguous)
+    # 1 x 1: four local permutations, no exchange; in place costs the staging pass
+    assert est((1, 1), b) < est((1, 1), b, inplace=True)
+    assert est((1, 1), b, orders=default, inplace=True) == 0.0  # identical layouts in place: nothing to do
