@@ -52,8 +52,8 @@ struct FlagList {
 // stages of a staged exchange have landed, kFlagDone = everything of the call has landed.
 constexpr unsigned long long kFlagScale = 16;
 constexpr int kFlagBegun = 0, kFlagDone = (int)kFlagScale - 1;
-// epoch (device memory) += 1; *ready (may be null) = epoch * kFlagScale
-void launchEpochBegin(unsigned long long* epoch, unsigned long long* ready, hipStream_t stream);
+// epoch (device memory) += 1; every flag of `begun` = epoch * kFlagScale
+void launchEpochBegin(unsigned long long* epoch, const FlagList& begun, hipStream_t stream);
 // every flag = *epoch * kFlagScale + step
 void launchSignal(const unsigned long long* epoch, const FlagList& flags, hipStream_t stream, int step = kFlagDone);
 // returns (on the stream) when every flag >= *epoch * kFlagScale + step; after timeout_s seconds writes a code to *status

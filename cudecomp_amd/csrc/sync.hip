@@ -28,12 +28,13 @@ using u64 = unsigned long long;
 
 // A flag holds  call number * kFlagScale + step:  step 0 = "the call has begun" (ready flags), steps 1 .. kFlagScale-2 =
 // stages of a staged exchange that have completely landed, kFlagScale-1 = "everything of this call has landed".
-__global__ void epoch_begin_k(u64* epoch, u64* ready) {
-  if (threadIdx.x == 0) {
-    const u64 e = *epoch + 1;
-    *epoch = e;
-    if (ready) __hip_atomic_store(ready, e * kFlagScale, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+__global__ void epoch_begin_k(u64* epoch, const FlagList begun) {
+  // every lane reads the old value before lane 0 bumps it (one wave: the read precedes the write in program order)
+  const u64 e = *epoch + 1;
+  __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x == 0) *epoch = e;
+  const int i = threadIdx.x;
+  if (i < begun.n) __hip_atomic_store(begun.f[i], e * kFlagScale, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void signal_k(const u64* epoch, const FlagList flags, u64 step) {
@@ -124,8 +125,8 @@ void launchChecksum(const void* p, size_t bytes, unsigned long long* out2, hipSt
   CD_CHECK_HIP(hipGetLastError());
 }
 
-void launchEpochBegin(unsigned long long* epoch, unsigned long long* ready, hipStream_t stream) {
-  epoch_begin_k<<<1, 64, 0, stream>>>(epoch, ready);
+void launchEpochBegin(unsigned long long* epoch, const FlagList& begun, hipStream_t stream) {
+  epoch_begin_k<<<1, 64, 0, stream>>>(epoch, begun);
   CD_CHECK_HIP(hipGetLastError());
 }
 

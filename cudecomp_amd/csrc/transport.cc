@@ -123,6 +123,9 @@ class PeerContext {
     for (auto& pk : pool_) (void)hipFree(pk.base);  // parked workspaces: released with the library
     for (auto& kv : imports_)
       if (kv.second.mapped) (void)hipIpcCloseMemHandle(kv.second.mapped);
+    for (int p = 0; p < (int)flag_base_.size(); ++p)
+      if (p != h_->rank && flag_base_[p]) (void)hipIpcCloseMemHandle(flag_base_[p]);
+    if (flag_mem_) (void)hipFree(flag_mem_);
     if (verify_count_) (void)hipFree(verify_count_);
     for (hipStream_t s : copy_streams_) (void)hipStreamDestroy(s);
     for (hipEvent_t e : copy_events_) (void)hipEventDestroy(e);
@@ -353,8 +356,79 @@ class PeerContext {
   }
   bool usable(const cudecompCommInfo& ci) const { return board_ && ci.ngroups == 1 && ci.barrier_slot >= 0; }
 
-  u64* dReady(int slot, int rank) { return reinterpret_cast<u64*>(dboard_ + flagRowOff(slot, rank)); }
-  u64* dLanded(int slot, int dst, int idx) { return reinterpret_cast<u64*>(dboard_ + flagRowOff(slot, dst)) + 1 + idx; }
+  // Where the flags live.  Board mode (fallback): row `rank` of the host-pinned board holds ready[rank] and
+  // landed[rank][*]; everybody polls and writes host memory (about 8 us per flag round trip between processes).
+  // Device mode: every rank owns a small UNCACHED device buffer, IPC-mapped into all ranks of the node once, when the
+  // transport comes up; a flag is always POLLED in the poller's own HBM and WRITTEN into the poller's buffer by whoever
+  // raises it (one posted store over xGMI) -- the counterpart of the reference's NVSHMEM signals in the symmetric heap
+  // (include/internal/cudecomp_kernels.cuh:51-84).  Row layout per slot: ready_from[nranks], landed[landed_n].
+  //   dReady(slot, r)        address I poll to see rank r's "begun" flag
+  //   dReadyAt(slot, m)      address rank m polls to see MINE (written by my epoch kernel)
+  //   dLanded(slot, dst, i)  landed flag i of rank dst: polled by dst (dst == me: local), written by the sender
+  u64* dReady(int slot, int rank) {
+    if (flag_base_.empty()) return reinterpret_cast<u64*>(dboard_ + flagRowOff(slot, rank));
+    return flag_base_[h_->rank] + (size_t)slot * flagRowWords() + rank;
+  }
+  u64* dReadyAt(int slot, int at_rank) {
+    if (flag_base_.empty()) return reinterpret_cast<u64*>(dboard_ + flagRowOff(slot, h_->rank));
+    return flag_base_[at_rank] + (size_t)slot * flagRowWords() + h_->rank;
+  }
+  u64* dLanded(int slot, int dst, int idx) {
+    if (flag_base_.empty()) return reinterpret_cast<u64*>(dboard_ + flagRowOff(slot, dst)) + 1 + idx;
+    return flag_base_[dst] + (size_t)slot * flagRowWords() + h_->nranks + idx;
+  }
+  bool deviceFlags() const { return !flag_base_.empty(); }
+  size_t flagRowWords() const { return (size_t)h_->nranks + landed_n_; }
+
+  // collective over the handle's communicator (called when the transport comes up on a job that has devices)
+  void setupDeviceFlags() {
+    if (!board_ || h_->nranks > 64 || std::getenv("CUDECOMP_FLAGS_IN_HOST_MEMORY")) return;
+    for (int r = 0; r < h_->nranks; ++r)
+      if (h_->hostnames[r] != h_->hostnames[h_->rank]) return;  // (multi-node jobs keep the per-node board)
+    struct Wire {
+      hipIpcMemHandle_t handle;
+      int ok;
+    };
+    Wire mine{};
+    const size_t bytes = ((size_t)kSlots * flagRowWords() * sizeof(u64) + 4095) / 4096 * 4096;
+    u64* buf = nullptr;
+    enablePeerAccessOnce();
+    bool ok = hipExtMallocWithFlags(reinterpret_cast<void**>(&buf), bytes, hipDeviceMallocUncached) == hipSuccess && buf;
+    if (ok) ok = hipMemset(buf, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (ok) ok = hipIpcGetMemHandle(&mine.handle, buf) == hipSuccess;
+    (void)hipGetLastError();
+    mine.ok = ok ? 1 : 0;
+    std::vector<Wire> all(h_->nranks);
+    h_->boot->allgather(&mine, all.data(), sizeof(Wire));
+    for (auto& w : all) ok = ok && w.ok;
+    std::vector<u64*> base(h_->nranks, nullptr);
+    if (ok) {
+      for (int p = 0; p < h_->nranks && ok; ++p) {
+        if (p == h_->rank) {
+          base[p] = buf;
+          continue;
+        }
+        void* m = nullptr;
+        ok = hipIpcOpenMemHandle(&m, all[p].handle, hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+        base[p] = static_cast<u64*>(m);
+      }
+      (void)hipGetLastError();
+    }
+    const bool all_ok = !h_->boot->allreduceOr(!ok);  // also: everybody has finished mapping
+    if (all_ok) {
+      flag_base_ = base;
+      flag_mem_ = buf;
+    } else {
+      for (int p = 0; p < h_->nranks; ++p)
+        if (p != h_->rank && base[p]) (void)hipIpcCloseMemHandle(base[p]);
+      if (buf) (void)hipFree(buf);
+      (void)hipGetLastError();
+    }
+    h_->boot->barrier();
+    if (h_->rank == 0 && std::getenv("CUDECOMP_VERBOSE"))
+      fprintf(stderr, "CUDECOMP: one-sided exchange flags live in %s\n", all_ok ? "device memory (polled locally, written by the peer)"
+                                                                              : "the host-pinned board");
+  }
   u64* dStatus() { return reinterpret_cast<u64*>(dboard_ + status_off_ + (size_t)h_->rank * 64); }
   // a wait kernel of an earlier call gave up: report it now (the data of that call is incomplete)
   void checkStatus() {
@@ -466,6 +540,12 @@ class PeerContext {
     for (int i = 0; i < 1 + landed_n_; ++i)  // (flags hold call * kFlagScale + step: round up to whole calls)
       v = std::max<uint64_t>(v, (reinterpret_cast<const std::atomic<uint64_t>*>(row + i)->load() + kFlagScale - 1) / kFlagScale);
     for (int par = 0; par < 2; ++par) v = std::max<uint64_t>(v, mail(slot, h_->rank, par).seq.load());
+    if (!flag_base_.empty()) {  // flags in device memory: my row of this slot (everything I enqueued has drained)
+      std::vector<u64> mine(flagRowWords());
+      if (hipMemcpy(mine.data(), flag_mem_ + (size_t)slot * flagRowWords(), mine.size() * sizeof(u64), hipMemcpyDeviceToHost) == hipSuccess)
+        for (u64 f : mine) v = std::max<uint64_t>(v, (f + kFlagScale - 1) / kFlagScale);
+      else (void)hipGetLastError();
+    }
     return v;
   }
 
@@ -640,6 +720,8 @@ class PeerContext {
   std::map<std::pair<int, uint64_t>, Import> imports_;
   std::vector<hipStream_t> copy_streams_;
   std::vector<hipEvent_t> copy_events_;
+  std::vector<u64*> flag_base_;  // device-memory flags: base of every rank's flag buffer as mapped here (empty: board mode)
+  u64* flag_mem_ = nullptr;      // my own
   struct Parked {
     char* base;
     size_t bytes;
@@ -797,7 +879,11 @@ void peerMeasureLink(cudecompHandle_t h) {
     const double t_sdma = h->boot->allreduceMax(ms[0]), t_cu = h->boot->allreduceMax(ms[1]);
     h->link_gbps_sdma = t_sdma > 0 ? bytes / (t_sdma * 1e-3) / 1e9 : 0;
     h->link_gbps_cu = t_cu > 0 ? bytes / (t_cu * 1e-3) / 1e9 : 0;
-    if (!h->peer_copy_engine_pinned) h->peer_copy_engine = (h->link_gbps_cu > 1.05 * h->link_gbps_sdma) ? 1 : 0;
+    // Ranks that SHARE a device always copy with kernels: same-device "copies engines" are blit kernels anyway, and the
+    // kernel path needs one extra stream where the copy-engine path needs one per peer -- every stream is a hardware
+    // queue, and processes that together exceed the device's queue slots get time-sliced.
+    if (!h->peer_copy_engine_pinned)
+      h->peer_copy_engine = (!h->link_crosses_devices || h->link_gbps_cu > 1.05 * h->link_gbps_sdma) ? 1 : 0;
     if (h->rank == 0 && std::getenv("CUDECOMP_VERBOSE"))
       fprintf(stderr, "CUDECOMP: peer link probe (%s): copy engines %.1f GB/s, compute-unit copy %.1f GB/s per direction; using %s\n",
               h->link_crosses_devices ? "across GPUs" : "ranks share a GPU", h->link_gbps_sdma, h->link_gbps_cu,
@@ -816,6 +902,13 @@ void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
   }
   if (need_peer && !h->peer) {
     h->peer = std::make_shared<PeerContext>(h);  // touches the device on first use only
+    bool have_dev = true;
+    try {
+      ensureDevice(h);
+    } catch (const Error&) {
+      have_dev = false;
+    }
+    if (!h->boot->allreduceOr(!have_dev)) h->peer->setupDeviceFlags();  // (geometry-only jobs have no device)
     peerMeasureLink(h);
   }
 }
@@ -997,7 +1090,14 @@ PeerCall peerBegin(cudecompHandle_t h, cudecompCommInfo& ci, bool rendezvous, co
     call.direct = false;
   }
   call.epoch = pc.devEpoch(ci);
-  launchEpochBegin(call.epoch, pc.dReady(ci.barrier_slot, h->rank), stream);
+  FlagList begun;  // "my call has begun": where each member polls it (device flags) / my board cell (board mode)
+  if (pc.deviceFlags()) {
+    for (int m = 0; m < ci.nranks; ++m)
+      if (ci.global_ranks[m] != h->rank) begun.add(pc.dReadyAt(ci.barrier_slot, ci.global_ranks[m]));
+  } else {
+    begun.add(pc.dReadyAt(ci.barrier_slot, h->rank));
+  }
+  launchEpochBegin(call.epoch, begun, stream);
   return call;
 }
 
@@ -1025,25 +1125,55 @@ void peerAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan&
   // ONE wait for every receiver's ready flag on the caller's stream, then the copies fan out (see peerReadyGate)
   peerReadyGate(h, ci, p, call, stream);
   hipEvent_t go = pc.copyEvent(2 * P);  // chunks packed, receivers ready
-  for (int j = 1; j < P; ++j) {
-    const int d = p.schedule_dst[j];
-    hipStream_t cs = pc.copyStream(j);
+  const bool cu = h->peer_copy_engine == 1 && P > 1;
+  const int ncopy = cu ? 1 : P - 1;
+  if (cu) {
+    // compute-unit copies: ONE launch whose workgroups serve the destinations round robin feeds every link for the
+    // whole launch, on ONE extra stream (a stream per peer brings nothing here and costs a hardware queue each)
+    hipStream_t cs = pc.copyStream(0);
     CD_CHECK_HIP(hipStreamWaitEvent(cs, go, 0));
-    peerCopy(h, call.remote_recv[d] + p.remote_recv_off[d] * es, b.send + p.send_off[d] * es, (size_t)p.send_cnt[d] * es, cs);
+    std::vector<Move3D> moves;
+    std::vector<void*> dst_base;
     FlagList landed;
-    landed.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[d], h->rank));
+    void* bufs[3] = {b.send, nullptr, nullptr};
+    for (int j = 1; j < P; ++j) {
+      const int d = p.schedule_dst[j];
+      landed.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[d], h->rank));
+      if (p.send_cnt[d] == 0) continue;
+      Move3D r;
+      r.src_buf = BUF_IN;
+      r.src_off = p.send_off[d];
+      r.dst_off = p.remote_recv_off[d];
+      r.extent[0] = p.send_cnt[d];
+      r.ss[0] = r.ds[0] = 1;
+      r.peer = d;
+      moves.push_back(r);
+      dst_base.push_back(call.remote_recv[d]);
+    }
+    if (!moves.empty()) launchMoves(moves.data(), (int)moves.size(), bufs, es, cs, &h->tuning, nullptr, dst_base.data());
     launchSignal(call.epoch, landed, cs);
-    CD_CHECK_HIP(hipEventRecord(pc.copyEvent(j), cs));
+    CD_CHECK_HIP(hipEventRecord(pc.copyEvent(0), cs));
+  } else {
+    for (int j = 1; j < P; ++j) {
+      const int d = p.schedule_dst[j];
+      hipStream_t cs = pc.copyStream(j);
+      CD_CHECK_HIP(hipStreamWaitEvent(cs, go, 0));
+      peerCopy(h, call.remote_recv[d] + p.remote_recv_off[d] * es, b.send + p.send_off[d] * es, (size_t)p.send_cnt[d] * es, cs);
+      FlagList landed;
+      landed.add(pc.dLanded(ci.barrier_slot, ci.global_ranks[d], h->rank));
+      launchSignal(call.epoch, landed, cs);
+      CD_CHECK_HIP(hipEventRecord(pc.copyEvent(j), cs));
+    }
   }
   // my own chunk: a local copy (reference: comm_routines.h:405-410), or through the engine under test
   if (p.send_cnt[me])
     peerCopy(h, b.recv + p.recv_off[me] * es, b.send + p.send_off[me] * es, (size_t)p.send_cnt[me] * es, stream,
              h->self_exchange ? -1 : 0);
   FlagList incoming;
-  for (int j = 1; j < P; ++j) {
-    CD_CHECK_HIP(hipStreamWaitEvent(stream, pc.copyEvent(j), 0));
-    incoming.add(pc.dLanded(ci.barrier_slot, h->rank, ci.global_ranks[p.schedule_src[j]]));
-  }
+  if (cu) CD_CHECK_HIP(hipStreamWaitEvent(stream, pc.copyEvent(0), 0));
+  else
+    for (int j = 1; j <= ncopy; ++j) CD_CHECK_HIP(hipStreamWaitEvent(stream, pc.copyEvent(j), 0));
+  for (int j = 1; j < P; ++j) incoming.add(pc.dLanded(ci.barrier_slot, h->rank, ci.global_ranks[p.schedule_src[j]]));
   launchWait(call.epoch, incoming, pc.dStatus(), h->peer_timeout_s, stream);
 }
 
@@ -1199,7 +1329,7 @@ void peerStagedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommI
     }
     // ---- send stage k to every peer
     if (cu && P > 1) {
-      hipStream_t cs = pc.copyStream(1);
+      hipStream_t cs = pc.copyStream(0);
       CD_CHECK_HIP(hipStreamWaitEvent(cs, packedEvent(k), 0));
       if (k == 0) CD_CHECK_HIP(hipStreamWaitEvent(cs, go, 0));
       moves.clear();
@@ -1220,7 +1350,7 @@ void peerStagedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommI
       }
       if (!moves.empty()) launchMoves(moves.data(), (int)moves.size(), bufs, es, cs, &h->tuning, nullptr, dst_base.data());
       launchSignal(call.epoch, landed_all, cs, stepOf(k));
-      if (k == K - 1) CD_CHECK_HIP(hipEventRecord(pc.copyEvent(1), cs));
+      if (k == K - 1) CD_CHECK_HIP(hipEventRecord(pc.copyEvent(0), cs));
     } else {
       for (int j = 1; j < P; ++j) {
         const int d = plan.schedule_dst[j];
@@ -1248,7 +1378,9 @@ void peerStagedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommI
     for (const Move3D& m : plan.unpack) moves.push_back(stageOfMove(m, ax, k, K));
     if (!moves.empty()) launchMoves(moves.data(), (int)moves.size(), bufs, es, stream, &h->tuning);
   }
-  for (int j = 1; j <= ncopy; ++j) CD_CHECK_HIP(hipStreamWaitEvent(stream, pc.copyEvent(j), 0));  // send area reusable
+  if (cu && P > 1) CD_CHECK_HIP(hipStreamWaitEvent(stream, pc.copyEvent(0), 0));  // send area reusable
+  else
+    for (int j = 1; j <= ncopy; ++j) CD_CHECK_HIP(hipStreamWaitEvent(stream, pc.copyEvent(j), 0));
 }
 
 void alltoallExchange(cudecompHandle_t h, cudecompGridDesc_t, cudecompCommInfo& ci, const TransposePlan& plan,
@@ -1369,10 +1501,11 @@ void peerHaloExchange(cudecompHandle_t h, cudecompGridDesc_t gd, const HaloExcha
   // overlapped sequence: the caller placed it behind the first pack, each face also waits for its own pack
   if (!ready_ev) ready_ev = haloReadyGate(h, gd, x, call, stream);
   FlagList incoming;
+  const bool one_stream = h->peer_copy_engine == 1;  // kernel copies: both faces share one extra stream (see peerAlltoall)
   for (int i = 0; i < 2; ++i) {
     if (x.neighbor[i] == -1) continue;
     const int m = memberOf(ci, x.neighbor[i]);
-    hipStream_t cs = pc.copyStream(i);
+    hipStream_t cs = pc.copyStream(one_stream ? 0 : i);
     if (packed) CD_CHECK_HIP(hipStreamWaitEvent(cs, packed[i], 0));
     CD_CHECK_HIP(hipStreamWaitEvent(cs, ready_ev, 0));
     FlagList landed;

@@ -24,14 +24,9 @@ def _binary(name):
     return path
 
 
-def _run(binary, nranks, lines, env=None, _repeat_of_known_flake=False):
+def _run(binary, nranks, lines, env=None):
     """Runs the case list through the native test program (reference protocol: every case PASSED, "Passed all tests.").
-
-    KNOWN OPEN ISSUE (scripts/probe/stress_eight_ranks.py): with EIGHT ranks time-sharing one GPU
-    about one transpose in 600 delivers a stale slice in the first hop of a fresh descriptor; four ranks never do.  So
-    that this rare event does not hide everything the suite checks after it, an 8-rank run with at most two failing
-    cases repeats exactly those cases once: a defect in the library fails again (and fails the test), the rare event
-    is logged to gpurun_out/known_flake_eight_ranks.log and reported as a warning -- never silently."""
+    Every failure is a failure: nothing is repeated."""
     with tempfile.NamedTemporaryFile("w", suffix="_cases.txt", delete=False) as f:
         f.write("\n".join(lines) + "\n")
         path = f.name
@@ -46,18 +41,6 @@ def _run(binary, nranks, lines, env=None, _repeat_of_known_flake=False):
         with open(os.path.join(ROOT, "gpurun_out", "native_failure_%s_%d.log" % (binary, os.getpid())), "w") as f:
             for r, text in enumerate(logs):
                 f.write("===== rank %d =====\n%s\n" % (r, text[-20000:]))
-        if nranks == 8 and not _repeat_of_known_flake and "Failing cases:" in out:
-            tail = out[out.index("Failing cases:"):].splitlines()[1:]
-            failing = [l.strip().split(" ", 1)[1].strip() for l in tail
-                       if " " in l.strip() and l.strip().split(" ", 1)[0].endswith(binary)]
-            if 0 < len(failing) <= 2 and out.count(" PASSED") == len(lines) - len(failing):
-                import warnings
-                msg = "%s on 8 ranks: %d of %d cases failed once and are repeated (known open issue, DESIGN.md section 9):\n  %s" % (
-                    binary, len(failing), len(lines), "\n  ".join(failing))
-                with open(os.path.join(ROOT, "gpurun_out", "known_flake_eight_ranks.log"), "a") as f:
-                    f.write(msg + "\n")
-                warnings.warn(msg)
-                return _run(binary, nranks, failing, env, _repeat_of_known_flake=True)
     assert ok, out[-3000:]
 
 
