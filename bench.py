@@ -415,14 +415,9 @@ def main():
         os.environ.setdefault("CUDECOMP_BOOTSTRAP_TIMEOUT", "120")
         # pencils of this benchmark live in cudecompMalloc memory: let the autotuner measure NVSHMEM_SM's direct put
         os.environ.setdefault("CUDECOMP_AUTOTUNE_LIBRARY_BUFFERS", "1")
-        # the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); an exchange
-        # with 7 peers runs 7 copy streams beside the caller's: give them queues of their own (must be set before the
-        # runtime starts, i.e. before torch is imported)
-        # -- but only with a GPU per rank: ranks that SHARE a device (flow checks on a one-GPU box) oversubscribe its
-        # hardware queue slots that way, and the scheduler then time-slices the queues (measured: 4 ranks on one GPU,
-        # 11.6 ms per cycle with <= 4 queues per process, 50 ms with 8; profiles/r02_tuning.md)
-        if gpus_on_this_host() >= world:
-            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # (no GPU_MAX_HW_QUEUES setting any more: the one-sided transport never parks a wait kernel on a copy stream and,
+        # with kernel copies, uses ONE copy stream beside the caller's, so the runtime's default of 4 hardware queues per
+        # process is enough -- and ranks that share a device must not exceed its queue slots)
     import torch
     import torch.distributed as dist
 

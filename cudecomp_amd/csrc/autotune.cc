@@ -331,11 +331,13 @@ void autotuneTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecomp
     // most promising grid first: later, slower grids are then cut off after their first trial
     std::vector<std::pair<double, std::array<int32_t, 2>>> ranked;
     for (auto& pd : grids) {
-      GridShape s = gd->shape;
+      GridShape s = gd->shape;  // (not synchronised with the config yet at this point: fill every field)
       for (int i = 0; i < 3; ++i) {
         s.gdims[i] = gd->config.gdims[i];
         s.gdims_dist[i] = gd->config.gdims_dist[i];
+        for (int j = 0; j < 3; ++j) s.mem_order[i][j] = gd->config.transpose_mem_order[i][j];
       }
+      s.col_major = gd->config.rank_order == CUDECOMP_RANK_ORDER_COL_MAJOR;
       s.pdims = pd;
       // (grids are ordered by their best backend's estimate)
       double best_est = 1e300;
