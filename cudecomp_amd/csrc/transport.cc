@@ -1092,8 +1092,8 @@ PeerCall peerBegin(cudecompHandle_t h, cudecompCommInfo& ci, bool rendezvous, co
   call.epoch = pc.devEpoch(ci);
   FlagList begun;  // "my call has begun": where each member polls it (device flags) / my board cell (board mode)
   if (pc.deviceFlags()) {
-    for (int m = 0; m < ci.nranks; ++m)
-      if (ci.global_ranks[m] != h->rank) begun.add(pc.dReadyAt(ci.barrier_slot, ci.global_ranks[m]));
+    // (my own buffer too: a one-member communicator in the self-exchange test mode waits for itself)
+    for (int m = 0; m < ci.nranks; ++m) begun.add(pc.dReadyAt(ci.barrier_slot, ci.global_ranks[m]));
   } else {
     begun.add(pc.dReadyAt(ci.barrier_slot, h->rank));
   }
