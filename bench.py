@@ -415,6 +415,8 @@ def main():
         os.environ.setdefault("CUDECOMP_BOOTSTRAP_TIMEOUT", "120")
         # pencils of this benchmark live in cudecompMalloc memory: let the autotuner measure NVSHMEM_SM's direct put
         os.environ.setdefault("CUDECOMP_AUTOTUNE_LIBRARY_BUFFERS", "1")
+        # every candidate of the sweep is reported with the analytic prior next to its measurement (config.also_measured)
+        os.environ.setdefault("CUDECOMP_AUTOTUNE_PRINT_MODEL", "1")
         # (no GPU_MAX_HW_QUEUES setting any more: the one-sided transport never parks a wait kernel on a copy stream and,
         # with kernel copies, uses ONE copy stream beside the caller's, so the runtime's default of 4 hardware queues per
         # process is enough -- and ranks that share a device must not exceed its queue slots)

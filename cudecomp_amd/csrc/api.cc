@@ -265,7 +265,9 @@ void buildCommInfo(cudecompHandle_t h, cudecompGridDesc_t gd) {
     // counters of the row continue above anything a member has ever seen there (nothing is reset, see internal.h)
     uint64_t high = 0;
     if (ci.barrier_slot >= 0) high = std::max<uint64_t>(h->slot_high[ci.barrier_slot], peerSlotHigh(h, ci.barrier_slot));
-    if (ci.nranks > 1) high = (uint64_t)ci.boot->allreduceMaxI64((int64_t)high);
+    // over ALL ranks of the handle, not only the new members: the row may hold values written by ranks that shared the
+    // row's previous communicator with a member but are not members now
+    if (h->nranks > 1) high = (uint64_t)h->boot->allreduceMaxI64((int64_t)high);
     ci.barrier_epoch = ci.mail_seq = ci.epoch_base = high;
   }
 }

@@ -123,6 +123,7 @@ class PeerContext {
     for (auto& pk : pool_) (void)hipFree(pk.base);  // parked workspaces: released with the library
     for (auto& kv : imports_)
       if (kv.second.mapped) (void)hipIpcCloseMemHandle(kv.second.mapped);
+    for (char* q : retired_imports_) (void)hipIpcCloseMemHandle(q);
     for (int p = 0; p < (int)flag_base_.size(); ++p)
       if (p != h_->rank && flag_base_[p]) (void)hipIpcCloseMemHandle(flag_base_[p]);
     if (flag_mem_) (void)hipFree(flag_mem_);
@@ -385,6 +386,7 @@ class PeerContext {
     if (!board_ || h_->nranks > 64 || std::getenv("CUDECOMP_FLAGS_IN_HOST_MEMORY")) return;
     for (int r = 0; r < h_->nranks; ++r)
       if (h_->hostnames[r] != h_->hostnames[h_->rank]) return;  // (multi-node jobs keep the per-node board)
+    const auto t_setup = std::chrono::steady_clock::now();
     struct Wire {
       hipIpcMemHandle_t handle;
       int ok;
@@ -426,8 +428,9 @@ class PeerContext {
     }
     h_->boot->barrier();
     if (h_->rank == 0 && std::getenv("CUDECOMP_VERBOSE"))
-      fprintf(stderr, "CUDECOMP: one-sided exchange flags live in %s\n", all_ok ? "device memory (polled locally, written by the peer)"
-                                                                              : "the host-pinned board");
+      fprintf(stderr, "CUDECOMP: one-sided exchange flags live in %s (set-up %.1f ms)\n",
+              all_ok ? "device memory (polled locally, written by the peer)" : "the host-pinned board",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_setup).count());
   }
   u64* dStatus() { return reinterpret_cast<u64*>(dboard_ + status_off_ + (size_t)h_->rank * 64); }
   // a wait kernel of an earlier call gave up: report it now (the data of that call is incomplete)
@@ -540,12 +543,8 @@ class PeerContext {
     for (int i = 0; i < 1 + landed_n_; ++i)  // (flags hold call * kFlagScale + step: round up to whole calls)
       v = std::max<uint64_t>(v, (reinterpret_cast<const std::atomic<uint64_t>*>(row + i)->load() + kFlagScale - 1) / kFlagScale);
     for (int par = 0; par < 2; ++par) v = std::max<uint64_t>(v, mail(slot, h_->rank, par).seq.load());
-    if (!flag_base_.empty()) {  // flags in device memory: my row of this slot (everything I enqueued has drained)
-      std::vector<u64> mine(flagRowWords());
-      if (hipMemcpy(mine.data(), flag_mem_ + (size_t)slot * flagRowWords(), mine.size() * sizeof(u64), hipMemcpyDeviceToHost) == hipSuccess)
-        for (u64 f : mine) v = std::max<uint64_t>(v, (f + kFlagScale - 1) / kFlagScale);
-      else (void)hipGetLastError();
-    }
+    // (flags in device memory are not read back: whatever anybody wrote into my buffer carries that rank's call number
+    // on the communicator that used the slot, which that rank reports itself -- buildCommInfo reduces over ALL ranks)
     return v;
   }
 
@@ -631,10 +630,12 @@ class PeerContext {
     auto it = imports_.find(key);
     if (it != imports_.end() &&
         (it->second.bytes != d.alloc_bytes || std::memcmp(&it->second.handle, &d.handle, sizeof(d.handle)) != 0)) {
-      // the owner freed that allocation and made a new one at the same address: drop the stale mapping (nothing of
-      // mine can still be in flight into memory its owner has already released, but make sure)
+      // the owner freed that allocation and made a new one at the same address.  The old mapping is RETIRED, not closed:
+      // closing a mapping right before importing its successor is the sequence that can hand back the predecessor's
+      // memory on this platform, while importers that never close are safe (scripts/probe/ipc_remap_probe.cpp, modes
+      // 1 vs 257).  Retired mappings are closed with the transport.
       (void)hipDeviceSynchronize();
-      if (it->second.mapped) (void)hipIpcCloseMemHandle(it->second.mapped);
+      if (it->second.mapped) retired_imports_.push_back(it->second.mapped);
       imports_.erase(it);
       it = imports_.end();
     }
@@ -718,6 +719,7 @@ class PeerContext {
   int64_t next_region_id_ = 0;
   std::map<char*, Export> exports_;
   std::map<std::pair<int, uint64_t>, Import> imports_;
+  std::vector<char*> retired_imports_;
   std::vector<hipStream_t> copy_streams_;
   std::vector<hipEvent_t> copy_events_;
   std::vector<u64*> flag_base_;  // device-memory flags: base of every rank's flag buffer as mapped here (empty: board mode)

@@ -736,3 +736,34 @@ def halo_timed(rank, nranks, args):
         torch.cuda.empty_cache()
     cd.cudecompGridDescDestroy(h, gd)
     return out
+
+
+def small_cycle_latency(rank, nranks, args):
+    """Latency of the flag-ordered exchanges: a tiny grid, many back-to-back cycles, ms per transpose (the data is a few
+    KiB, so the time is launches + flag round trips)."""
+    import time
+    h, gd, g = _setup(rank, nranks, args)
+    es = 8
+    pin = [cd.cudecompGetPencilInfo(h, gd, ax) for ax in range(3)]
+    nel = max(p.size for p in pin)
+    work = cd.cudecompMalloc(h, gd, max(cd.cudecompGetTransposeWorkspaceSize(h, gd), 1) * es)
+    a = torch.zeros(nel, dtype=torch.float64, device="cuda")
+    b = torch.zeros(nel, dtype=torch.float64, device="cuda")
+    st = G.stream_ptr()
+
+    def cycles(n):
+        cur, nxt = a, b
+        for _ in range(n):
+            for op in cd.OPS:
+                cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DOUBLE, stream=st)
+                cur, nxt = nxt, cur
+    cycles(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = args.get("cycles", 200)
+    cycles(n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cd.cudecompFree(h, gd, work)
+    cd.cudecompGridDescDestroy(h, gd)
+    return {"us_per_transpose": dt / (4 * n) * 1e6}
