@@ -382,6 +382,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     if (const char* v = std::getenv("CUDECOMP_RCCL_NATIVE_ALLTOALL")) h->rccl_native_alltoall = std::strtol(v, nullptr, 10) != 0;
     h->direct_put = !envIsOne("CUDECOMP_DISABLE_DIRECT_PUT");
     h->debug_verify_exchange = envIsOne("CUDECOMP_DEBUG_VERIFY_EXCHANGE");
+    if (const char* v = std::getenv("CUDECOMP_PIPELINE_MIN_STAGE_MIB")) h->pipeline_min_stage_bytes = std::strtoll(v, nullptr, 10) << 20;
     if (const char* v = std::getenv("CUDECOMP_PIPELINE_STAGES")) {
       const long k = std::strtol(v, nullptr, 10);
       if (k >= 1 && k <= 15) h->pipeline_stages = (int)k;

@@ -261,7 +261,7 @@ double estimateTransposeCycleMs(cudecompHandle_t h, const GridShape& g, int es, 
   for (int op = 0; op < 4; ++op) {
     const int P = (op == 0 || op == 3) ? g.pdims[0] : g.pdims[1];
     const bool ip = inplace && inplace[op];
-    int passes = 1;
+    int passes = 1, staged_k = 1;
     bool staged = false;
     try {
       const TransposePlan p = buildTransposePlan(g, h->rank, (TransposeOp)op, zero, zero, zero, zero, ip, traits, std::max(P, 1));
@@ -270,6 +270,7 @@ double estimateTransposeCycleMs(cudecompHandle_t h, const GridShape& g, int es, 
         const bool direct = fused && library_buffers && h->direct_put && !ip && !p.direct.empty();
         passes = direct ? 1 : ((fused || !p.pack.empty()) ? 1 : 0) + (p.unpack.empty() ? 0 : 1);
         staged = traits.pipelined && traits.symmetric_recv;
+        staged_k = stageCount(p, h->pipeline_stages, es, h->pipeline_min_stage_bytes);
       } else {
         passes = (int)(!p.pack.empty()) + (int)(!p.unpack.empty());
       }
@@ -284,7 +285,7 @@ double estimateTransposeCycleMs(cudecompHandle_t h, const GridShape& g, int es, 
       comm = on_node ? chunk / link : chunk * (P - 1) / nic;
     }
     if (fused && P > 1) total += std::max(comm, 2.0 * pencil / hbm) + (passes > 1 ? 2.0 * pencil / hbm : 0.0);  // the put IS the pack
-    else if (staged) total += std::max(local, comm) + std::min(local, comm) / std::max(1, h->pipeline_stages);
+    else if (staged) total += std::max(local, comm) + std::min(local, comm) / std::max(1, staged_k);
     else total += local + comm;
   }
   return total * 1e3;

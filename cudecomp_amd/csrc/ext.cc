@@ -411,7 +411,9 @@ cudecompResult_t cudecompExtRunLocalPhases(const cudecompExtGridSpec_t* grid, in
     // pipeline, transpose.h:470-513, 683-744)
     int stages = 4;
     if (const char* v = std::getenv("CUDECOMP_PIPELINE_STAGES")) stages = (int)std::strtol(v, nullptr, 10);
-    const int K = (int)std::max<i64>(1, std::min<i64>({(i64)stages, p.stage_limit, (i64)kFlagDone}));
+    i64 min_stage = (i64)8 << 20;
+    if (const char* v = std::getenv("CUDECOMP_PIPELINE_MIN_STAGE_MIB")) min_stage = std::strtoll(v, nullptr, 10) << 20;
+    const int K = stageCount(p, stages, es, min_stage);
     auto run = [&](const std::vector<Move3D>& moves) {
       if (moves.empty()) return;
       if (traits.pipelined && traits.symmetric_recv && p.exchange) {

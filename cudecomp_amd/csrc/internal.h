@@ -78,6 +78,7 @@ struct cudecompHandle {
   bool rccl_native_alltoall = true;   // CUDECOMP_RCCL_NATIVE_ALLTOALL=0: grouped send/recv even where ncclAllToAll applies
   bool debug_verify_exchange = false;  // CUDECOMP_DEBUG_VERIFY_EXCHANGE=1: checksum what one-sided exchanges delivered (host-synchronous)
   bool direct_put = true;             // CUDECOMP_DISABLE_DIRECT_PUT=1: NVSHMEM_SM always lands in the receive area + unpack
+  long long pipeline_min_stage_bytes = 8ll << 20;  // CUDECOMP_PIPELINE_MIN_STAGE_MIB: no stage smaller than this
   int pipeline_stages = 4;            // CUDECOMP_PIPELINE_STAGES: stages of the one-sided pipelined exchange (1..15)
   double peer_timeout_s = 120.0;      // CUDECOMP_PEER_TIMEOUT: how long a rank waits for a peer (host rendezvous, device flags)
   int peer_copy_engine = 0;           // 0 = copy engines (hipMemcpyAsync), 1 = compute-unit copy kernel; CUDECOMP_PEER_COPY_ENGINE

@@ -135,6 +135,7 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
   if (W[2] == ax.a) p.stage_limit = *std::min_element(splits_a.begin(), splits_a.end());
   else if (W[2] == ax.b) p.stage_limit = *std::min_element(splits_b.begin(), splits_b.end());
   else p.stage_limit = Sa[ax.c];
+  p.stage_elements = maxPencilElements(g, ax.a);
   p.send_buf = skip_pack ? BUF_IN : BUF_WORK;
   p.send_base = 0;
   p.recv_buf = skip_unpack ? BUF_OUT : BUF_WORK;
@@ -202,6 +203,11 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
     }
   }
   return p;
+}
+
+int stageCount(const TransposePlan& p, int wanted, int es, i64 min_stage_bytes) {
+  const i64 by_size = min_stage_bytes > 0 ? std::max<i64>(1, p.stage_elements * es / min_stage_bytes) : (i64)wanted;
+  return (int)std::max<i64>(1, std::min<i64>({(i64)wanted, p.stage_limit, (i64)14, by_size}));
 }
 
 Move3D stageOfMove(const Move3D& m, int axis, int k, int K) {

@@ -65,6 +65,7 @@ struct TransposePlan {
   // (the same number on every member: an upper bound for the number of stages everybody can agree on without talking).
   int stage_axis = 2;
   i64 stage_limit = 1;
+  i64 stage_elements = 0;  // largest pencil of the decomposition (the same number on every rank): staging is sized by it
   std::vector<i64> send_n, recv_n;  // extent along stage_axis of the chunk for member d / from member s
 
   // Direct-to-destination put (one-sided transports, out of place): move `direct[j]` takes the slab of my input that
@@ -98,6 +99,11 @@ struct HaloPlan {
 
 HaloPlan buildHaloPlan(const GridShape& g, int rank, int axis, int dim, const int32_t* halo, const bool* periods,
                        const int32_t* pad, bool force_packed, bool self_exchange = false);
+
+// Number of stages every member of the communicator arrives at without talking: at most `wanted`, at most the smallest
+// chunk extent, at most 14 (flag steps), and no stage smaller than `min_stage_bytes` of the largest pencil (below that the extra
+// launches cost more than the overlap gains).
+int stageCount(const TransposePlan& p, int wanted, int es, i64 min_stage_bytes = (i64)8 << 20);
 
 // range k of K (equal parts, the remainder spread over the first ranges) of the extent of `m` along global axis `axis`
 Move3D stageOfMove(const Move3D& m, int axis, int k, int K);

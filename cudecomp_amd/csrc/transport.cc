@@ -1301,7 +1301,7 @@ void peerStagedExchange(cudecompHandle_t h, cudecompGridDesc_t gd, cudecompCommI
   (void)gd;
   PeerContext& pc = peerOf(h, ci);
   const int P = plan.nranks, me = plan.comm_rank, ax = plan.stage_axis;
-  const int K = (int)std::max<i64>(1, std::min<i64>({(i64)h->pipeline_stages, plan.stage_limit, (i64)kFlagDone}));
+  const int K = stageCount(plan, h->pipeline_stages, es, h->pipeline_min_stage_bytes);
   auto stepOf = [&](int k) { return k == K - 1 ? kFlagDone : k + 1; };
   // events: [0, P) last copy of each copy stream, 2P "go", then one "packed" event per stage
   auto packedEvent = [&](int k) { return pc.copyEvent(2 * P + 2 + k); };

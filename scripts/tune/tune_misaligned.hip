@@ -27,8 +27,8 @@ struct Shape {
   long long ei, ej, ek, sj, sk, di, dk, soff, doff;
 };
 
-template <int TI, int TJ, int LDM, int STM, int JFIRST, int L = 16>
-__global__ __launch_bounds__(256) void win_kernel(const double* __restrict__ src, double* __restrict__ dst, Shape s,
+template <int TI, int TJ, int LDM, int STM, int JFIRST, int L = 16, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void win_kernel(const double* __restrict__ src, double* __restrict__ dst, Shape s,
                                                   unsigned ti_n, unsigned tj_n) {
   // L = elements per alignment unit of the store windows (16 = 128-B line, 8 = 64 B, 4 = 32 B)
   constexpr int ROWS = TJ + L - 1;  // source rows a tile may need
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void win_kernel(const double* __restrict__ src
   double* dp = dst + s.doff + k * s.dk;
   const int tid = threadIdx.x;
   if (LDM == 2) {  // 16-byte ALIGNED loads: shift every row's vectors by its element phase, one scalar load closes the row
-    constexpr int TPR = TI / 2, RPP = 256 / TPR;
+    constexpr int TPR = TI / 2, RPP = NTHR / TPR;
     const int l = tid % TPR, lj = tid / TPR;
     const unsigned long long sbase = (unsigned long long)(uintptr_t)sp / 8;
 #pragma unroll
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void win_kernel(const double* __restrict__ src
       }
     }
   } else {  // load: ROWS source rows x TI elements, 2 elements per lane
-    constexpr int TPR = TI / 2, RPP = 256 / TPR;
+    constexpr int TPR = TI / 2, RPP = NTHR / TPR;
     const int li = (tid % TPR) * 2, lj = tid / TPR;
 #pragma unroll
     for (int p = 0; p < (ROWS + RPP - 1) / RPP; ++p) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void win_kernel(const double* __restrict__ src
   }
   __syncthreads();
   {  // store: destination row i covers j in [bj*TJ - p_i, +TJ); 2 elements per lane, 16-B aligned
-    constexpr int TPO = TJ / 2, RPO = 256 / TPO;
+    constexpr int TPO = TJ / 2, RPO = NTHR / TPO;
     const int c = tid % TPO, lr = tid / TPO;
     const unsigned long long dbase = (unsigned long long)(uintptr_t)dp / 8;
 #pragma unroll
@@ -221,10 +221,10 @@ struct Ctx {
   cudecomp::KernelTuning tuning;
 };
 
-template <int TI, int TJ, int LDM, int STM, int JF, int L = 16>
+template <int TI, int TJ, int LDM, int STM, int JF, int L = 16, int NTHR = 256>
 static void launchWin(Ctx* c) {
   const unsigned ti = (unsigned)((c->s.ei + TI - 1) / TI), tj = (unsigned)((c->s.ej + L - 1 + TJ - 1) / TJ);
-  win_kernel<TI, TJ, LDM, STM, JF, L><<<dim3(ti * tj * (unsigned)c->s.ek), 256>>>(c->src, c->dst, c->s, ti, tj);
+  win_kernel<TI, TJ, LDM, STM, JF, L, NTHR><<<dim3(ti * tj * (unsigned)c->s.ek), NTHR>>>(c->src, c->dst, c->s, ti, tj);
 }
 
 template <int TI, int TJ, int LDM, int BODY, bool JF>
@@ -262,6 +262,12 @@ static void run(void* p) {
     case 13: launchWin<64, 64, 0, 1, 3, 8>(c); break;
     case 14: launchWin<64, 64, 2, 1, 0, 8>(c); break;
     case 15: launchWin<64, 64, 2, 1, 1, 8>(c); break;
+    case 16: launchWin<128, 64, 0, 1, 1, 8, 512>(c); break;
+    case 17: launchWin<128, 64, 0, 1, 0, 8, 512>(c); break;
+    case 18: launchWin<128, 32, 0, 1, 1, 8, 256>(c); break;
+    case 19: launchWin<64, 128, 0, 1, 1, 8, 512>(c); break;
+    case 20: launchWin<128, 32, 0, 1, 1, 8, 512>(c); break;
+    case 21: launchWin<64, 64, 0, 1, 1, 8, 512>(c); break;
   }
 }
 
@@ -309,7 +315,9 @@ int main() {
                       "win 64x64 NT/NT i-first", "win 64x64 cached/NT j-first", "win 64x64 NT/NT j-first",
                       "win 32x128 cached/NT j-first", "win 32x128 NT/NT j-first", "win 32x128 NT/NT i-first", "win 32x128 c/NT j-first, 64-B units",
                       "win 64x64 c/NT 64B walk i-first", "win 64x64 c/NT 64B walk j-first", "win 64x64 c/NT 64B walk 4x4",
-                      "win 64x64 c/NT 64B walk 8ix2j", "win 64x64 ALIGNED-LOADS/NT 64B i-first", "win 64x64 ALIGNED-LOADS/NT 64B j-first"};
+                      "win 64x64 c/NT 64B walk 8ix2j", "win 64x64 ALIGNED-LOADS/NT 64B i-first", "win 64x64 ALIGNED-LOADS/NT 64B j-first",
+                      "win 128x64 512thr c/NT 64B j-first", "win 128x64 512thr c/NT 64B i-first", "win 128x32 256thr c/NT 64B j-first",
+                      "win 64x128 512thr c/NT 64B j-first", "win 128x32 512thr c/NT 64B j-first", "win 64x64 512thr c/NT 64B j-first"};
   for (auto& c : cases) {
     const double bytes = 2.0 * c.s.ei * c.s.ej * c.s.ek * 8;
     printf("== %s: %lld x %lld x %lld, %.2f GB per launch\n", c.name, c.s.ei, c.s.ej, c.s.ek, bytes / 1e9);
@@ -317,7 +325,7 @@ int main() {
     CK(hipMemset(ref, 0, n * 8));
     run(&ctx);  // reference result from the library kernel
     CK(hipDeviceSynchronize());
-    for (int v = 0; v < 16; ++v) {
+    for (int v = (getenv("TUNE_FROM") ? atoi(getenv("TUNE_FROM")) : 0); v < 22; ++v) {
       Ctx x{src, dst, c.s, v, {}};
       CK(hipMemset(dst, 0, n * 8));
       const float ms = timeIt(run, &x);
