@@ -383,7 +383,13 @@ class PeerContext {
 
   // collective over the handle's communicator (called when the transport comes up on a job that has devices)
   void setupDeviceFlags() {
-    if (!board_ || h_->nranks > 64 || std::getenv("CUDECOMP_FLAGS_IN_HOST_MEMORY")) return;
+    // OPT-IN (CUDECOMP_FLAGS_IN_DEVICE_MEMORY=1).  Measured with ranks sharing one GPU (profiles/r03_tuning.md): per
+    // exchange the device flags are as fast or faster than the board, but eight ranks on one device ran the case sweeps
+    // 2.7x slower with them and, rarely, a wait kernel never saw a flag that had been raised (30-s device-side
+    // timeouts in two suite runs); the board has no such history, so it stays the default until the device flags can
+    // be qualified on a node with a GPU per rank.
+    const char* want = std::getenv("CUDECOMP_FLAGS_IN_DEVICE_MEMORY");
+    if (!board_ || h_->nranks > 64 || !want || std::strtol(want, nullptr, 10) != 1) return;
     for (int r = 0; r < h_->nranks; ++r)
       if (h_->hostnames[r] != h_->hostnames[h_->rank]) return;  // (multi-node jobs keep the per-node board)
     const auto t_setup = std::chrono::steady_clock::now();

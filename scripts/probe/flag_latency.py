@@ -13,7 +13,7 @@ from tests.mp import run_ranks  # noqa: E402
 out = {}
 for n, pd in ((2, (1, 2)), (4, (1, 4)), (8, (1, 8))):
     for backend, bname in ((cd.TRANSPOSE_COMM_NVSHMEM, "nvshmem"), (cd.TRANSPOSE_COMM_NVSHMEM_SM, "nvshmem_sm")):
-        for flags, env in (("device", {}), ("host", {"CUDECOMP_FLAGS_IN_HOST_MEMORY": "1"})):
+        for flags, env in (("device", {"CUDECOMP_FLAGS_IN_DEVICE_MEMORY": "1"}), ("host", {})):
             args = {"gdims": (16, 16, 16), "pdims": pd, "kind": 1, "transpose_backend": backend, "cycles": 200}
             res = run_ranks(n, "tests.gpu_bodies", "small_cycle_latency", args, timeout=300, extra_env=env)
             out["%d ranks %s %s flags" % (n, bname, flags)] = round(max(r["us_per_transpose"] for r in res), 1)
