@@ -408,6 +408,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->tuning.no_streaming = envIsOne("CUDECOMP_DISABLE_STREAMING_ACCESS");
     if (const char* v = std::getenv("CUDECOMP_INTERLEAVE_ROWS")) h->tuning.interleave_rows = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
     if (const char* v = std::getenv("CUDECOMP_WINDOW_STORES")) h->tuning.window_mode = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
+    if (const char* v = std::getenv("CUDECOMP_WINDOW_WIDE")) h->tuning.window_wide = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
     if (const char* v = std::getenv("CUDECOMP_TILE_WALK")) h->tuning.walk_order = (int)std::strtol(v, nullptr, 10);  // tuning aid
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))
       if (std::strtol(v, nullptr, 10) == 1) h->tuning.force_class = MOVE_GENERIC;

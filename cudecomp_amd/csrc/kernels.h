@@ -29,6 +29,7 @@ struct KernelTuning {
   int misaligned_store_mode = -1;  // tuning aid: streaming mode (0/1/2) for transposes with unaligned destination rows
   int stream_mode = -1;            // tuning aid: force the access mode (0..4, see kernels.hip) of large moves
   int interleave_rows = 1;         // batched row copies: workgroups serve the moves round robin (0: one move after the other)
+  int window_wide = 0;             // window kernel, 8-byte elements: 1 = 128 x 64 tiles with 512 threads (CUDECOMP_WINDOW_WIDE=1)
   int window_mode = -1;            // transposes onto rows off the 64-byte grid: -1 window kernel for moves >= 1 MiB, 0 never, 1 always
 };
 

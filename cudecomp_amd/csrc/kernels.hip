@@ -484,20 +484,20 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
 // accessed element-wise here (row pitch TI + 1: the column reads of the store phase spread over the banks).
 // e = {ei, ej, ek}; ss = {1, sj, sk}; ds = {di, 1, dk} (elements), as for transpose_kernel; t1 counts windows.
 // ---------------------------------------------------------------------------------------------
-template <int ES, int VW, int TI, int TJ, int STREAM>
-__global__ __launch_bounds__(kThreads) void transpose_window_kernel(const Batch b) {
+template <int ES, int VW, int TI, int TJ, int STREAM, int NT = kThreads>
+__global__ __launch_bounds__(NT) void transpose_window_kernel(const Batch b) {
   using E = Bytes<ES>;
   using V = Bytes<ES * VW>;
   constexpr int U = 64 / ES;            // elements per 64-byte unit
   constexpr int ROWS = TJ + U - 1;      // source rows a tile's windows can touch
   constexpr int PITCH = TI + 1;
   constexpr int TPR = TI / VW;          // lanes per source row segment
-  constexpr int RPP = kThreads / TPR;   // source rows per load pass
+  constexpr int RPP = NT / TPR;   // source rows per load pass
   constexpr int NP = (ROWS + RPP - 1) / RPP;
   constexpr int TPO = TJ / VW;          // lanes per destination row window
-  constexpr int RPO = kThreads / TPO;   // destination rows per store pass
+  constexpr int RPO = NT / TPO;   // destination rows per store pass
   constexpr int NPO = TI / RPO;
-  static_assert(kThreads % TPR == 0 && kThreads % TPO == 0 && TI % RPO == 0, "window mapping");
+  static_assert(NT % TPR == 0 && NT % TPO == 0 && TI % RPO == 0, "window mapping");
   __shared__ __attribute__((aligned(16))) E tile[ROWS * PITCH];
 
   int mi;
@@ -742,7 +742,11 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     if (j_first) c.p1 |= 2;
     // (window kernel, 4-byte elements: 64 x 128 tiles -- a 64-byte unit is 16 elements, the longer window halves the
     // share of overlap rows)
-    const int ti = (es == 16) ? 32 : 64, tj = (c.window && es == 4) ? 128 : ti;
+    // (window kernel, 8-byte elements, optional: 128 x 64 tiles with 512 threads -- 1-KiB source segments span nine
+    // lines instead of 2 x five; variant 102)
+    const bool wide = c.window && es == 8 && vw == 2 && tuning && tuning->window_wide == 1;
+    if (wide) c.variant = 102;
+    const int ti = (es == 16) ? 32 : (wide ? 128 : 64), tj = (c.window && es == 4) ? 128 : ((es == 16) ? 32 : 64);
     c.t0 = (unsigned int)((c.dm.e[0] + ti - 1) / ti);
     c.t1 = (unsigned int)((c.dm.e[1] + (c.window ? 64 / es - 1 : 0) + tj - 1) / tj);
     c.blocks = (unsigned long long)c.t0 * c.t1 * (unsigned long long)c.dm.e[2];
@@ -765,13 +769,14 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
 }
 
 template <int STREAM>
-void launchWindowT(int variant, int es, const Batch& b, unsigned int blocks, hipStream_t stream) {
+void launchWindowT(int variant, int es, const Batch& b, unsigned int blocks, hipStream_t stream, bool wide) {
   const dim3 grid(blocks), block(kThreads);
   if (es == 4) {
     if (variant == 4) transpose_window_kernel<4, 4, 64, 128, STREAM><<<grid, block, 0, stream>>>(b);
     else transpose_window_kernel<4, 1, 64, 128, STREAM><<<grid, block, 0, stream>>>(b);
   } else if (es == 8) {
-    if (variant == 2) transpose_window_kernel<8, 2, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
+    if (variant == 2 && wide) transpose_window_kernel<8, 2, 128, 64, STREAM, 512><<<grid, dim3(512), 0, stream>>>(b);
+    else if (variant == 2) transpose_window_kernel<8, 2, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
     else transpose_window_kernel<8, 1, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
   } else {
     transpose_window_kernel<16, 1, 32, 32, STREAM><<<grid, block, 0, stream>>>(b);
@@ -822,17 +827,18 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d>", window ? "rows_shifted_kernel" : "rows_kernel", variant,
              stream_access == 3 ? 3 : (stream_access >= 1 ? 1 : 0));
   else if (cls == MOVE_TRANSPOSE && window)
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_window_kernel<%d,%d,%d,%d,%d>", es, variant, es == 16 ? 32 : 64,
-             es == 16 ? 32 : (es == 4 ? 128 : 64), stream_access);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_window_kernel<%d,%d,%d,%d,%d>", es, variant % 100,
+             es == 16 ? 32 : (variant >= 100 ? 128 : 64), es == 16 ? 32 : (es == 4 ? 128 : 64), stream_access);
   else if (cls == MOVE_TRANSPOSE)
     snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_kernel<%d,%d,%d,%d,%d,%s>", es, variant, es == 16 ? 32 : 64,
              es == 16 ? 32 : 64, stream_access, swizzle ? "true" : "false");
   else
     snprintf(g_last_kernel, sizeof(g_last_kernel), "generic_kernel<%d,%s>", es, stream_access == 3 ? "true" : "false");
   if (cls == MOVE_TRANSPOSE && window) {
-    if (stream_access == 3) launchWindowT<3>(variant, es, b, blocks, stream);
-    else if (stream_access == 4 || stream_access == 2) launchWindowT<4>(variant, es, b, blocks, stream);
-    else launchWindowT<0>(variant, es, b, blocks, stream);
+    const bool wide = variant >= 100;
+    if (stream_access == 3) launchWindowT<3>(variant % 100, es, b, blocks, stream, wide);
+    else if (stream_access == 4 || stream_access == 2) launchWindowT<4>(variant % 100, es, b, blocks, stream, wide);
+    else launchWindowT<0>(variant % 100, es, b, blocks, stream, wide);
     return;
   }
   if (stream_access == 4) {  // cached loads + streaming stores (misaligned sources)

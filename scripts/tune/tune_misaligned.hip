@@ -343,6 +343,17 @@ int main() {
       const float ms = timeIt(run, &x);
       printf("  lib, streaming mode %d                %7.3f ms %6.0f GB/s\n", mode, ms, bytes / ms / 1e6);
     }
+    {  // the library's window kernel with 128 x 64 tiles and 512 threads (CUDECOMP_WINDOW_WIDE=1)
+      Ctx x{src, dst, c.s, 0, {}};
+      x.tuning.window_wide = 1;
+      CK(hipMemset(dst, 0, n * 8));
+      const float ms = timeIt(run, &x);
+      CK(hipMemset(bad, 0, 8));
+      diff<<<4096, 256>>>(dst, ref, n, bad);
+      unsigned long long hb = 0;
+      CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
+      printf("  lib, wide window tiles (128x64, 512)  %7.3f ms %6.0f GB/s  %s\n", ms, bytes / ms / 1e6, hb ? "WRONG" : "ok");
+    }
   }
   return 0;
 }
