@@ -4,8 +4,8 @@ mkdir -p gpurun_out/final3
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/final3
 REPO=$PWD
-( TUNE_FROM=99 timeout 200 scripts/tune/tune_misaligned ) > $O/tune_wide.log 2>&1; grep -E "==|wide|lib" $O/tune_wide.log | cut -c1-120
-( STRESS_ITERS=6 timeout 900 bash scripts/probe/count_queues.sh ) > $O/count_queues.log 2>&1; cat $O/count_queues.log | cut -c1-220
+
+( STRESS_ITERS=5 timeout 1200 bash scripts/probe/count_queues.sh ) > $O/count_queues.log 2>&1; cat $O/count_queues.log | cut -c1-220
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $REPO/$O/halo_$c -o halo -- python $REPO/benchmark/halo_bench.py > $REPO/$O/halo_$c.log 2>&1
@@ -27,3 +27,5 @@ for f in glob.glob("gpurun_out/final3/halo_*/**/*counter_collection.csv", recurs
 PY
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
 ( timeout 600 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err ); cut -c1-400 $O/bench_n1.json
+export CUDECOMP_PEER_TIMEOUT=30
+( time timeout 2400 python tests/test_gpu_runner_cases.py --full --ngpu8 ) > $O/reference_sweep_full_ngpu8.log 2>&1; tail -3 $O/reference_sweep_full_ngpu8.log | cut -c1-200

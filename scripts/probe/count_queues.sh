@@ -17,7 +17,8 @@ sample() {  # $1 = pid of the stress driver
   done
   echo "   KFD queues: max per process $maxper, max in total $maxtot"
 }
-for setting in "default:" "copy-engines(stream-per-peer):CUDECOMP_PEER_COPY_ENGINE=sdma" "device-flags:CUDECOMP_FLAGS_IN_DEVICE_MEMORY=1" "2-queues+copy-engines:CUDECOMP_PEER_COPY_ENGINE=sdma GPU_MAX_HW_QUEUES=2"; do
+# (tests/mp.py gives more than five ranks per device GPU_MAX_HW_QUEUES=2; the runtime's own default is 4)
+for setting in "runtime-default-queues:GPU_MAX_HW_QUEUES=4" "runtime-default-queues+copy-engines(stream-per-peer):GPU_MAX_HW_QUEUES=4 CUDECOMP_PEER_COPY_ENGINE=sdma" "runtime-default-queues+device-flags:GPU_MAX_HW_QUEUES=4 CUDECOMP_FLAGS_IN_DEVICE_MEMORY=1" "2-queues+copy-engines:CUDECOMP_PEER_COPY_ENGINE=sdma GPU_MAX_HW_QUEUES=2" "2-queues(harness-default):GPU_MAX_HW_QUEUES=2"; do
   name=${setting%%:*}; envs=${setting#*:}
   echo "== $name ($envs)"
   python scripts/probe/stress_eight_ranks.py mix ${STRESS_ITERS:-6} $envs > /tmp/cq_$name.log 2>&1 &

@@ -38,6 +38,33 @@ def free_port():
     raise RuntimeError("no free TCP port found")
 
 
+def gpus_on_this_host():
+    """GPU agents the kernel driver lists (no runtime needed)."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(f) as fh:
+                for line in fh:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def shared_device_env(nranks, env):
+    """Ranks that SHARE a GPU must not oversubscribe its hardware queue slots: every process may open up to
+    GPU_MAX_HW_QUEUES (default 4) queues, the device has about 24 slots for user queues, and beyond them the scheduler
+    time-slices the queues -- runs get 4-5x slower and, rarely, a kernel's results become visible late (DESIGN.md section
+    9 B: measured with and without this setting, profiles/r03_stress_*.log, r03_count_queues.log).  More than five ranks
+    per device therefore run with two queues per process.  One rank per GPU (production) is never touched."""
+    ngpu = max(gpus_on_this_host(), 1)
+    per_gpu = (nranks + ngpu - 1) // ngpu
+    if per_gpu > 5:
+        env.setdefault("GPU_MAX_HW_QUEUES", "2")
+
+
 def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_rank_env=None):
     port_a, port_b = free_port(), free_port()
     outdir = tempfile.mkdtemp(prefix="cudecomp_mp_")
@@ -51,6 +78,7 @@ def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_
         # the staged pipeline of the one-sided transports normally keeps stages above 8 MiB; the tests' small grids must
         # run it with several stages too
         env.setdefault("CUDECOMP_PIPELINE_MIN_STAGE_MIB", "0")
+        shared_device_env(nranks, env)
         if extra_env:
             env.update(extra_env)
         if per_rank_env:
@@ -107,6 +135,7 @@ def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
                     "MASTER_PORT": str(port_a), "CUDECOMP_BOOTSTRAP_PORT": str(port_b),
                     "CUDECOMP_BOOTSTRAP_TIMEOUT": "60", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "CUDECOMP_TEST_JOB": job})
         env.setdefault("CUDECOMP_PIPELINE_MIN_STAGE_MIB", "0")  # small grids still run several pipeline stages
+        shared_device_env(nranks, env)
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([str(a) for a in argv], env=env, cwd=ROOT, stdout=subprocess.PIPE,
