@@ -54,15 +54,18 @@ def gpus_on_this_host():
 
 
 def shared_device_env(nranks, env):
-    """Ranks that SHARE a GPU must not oversubscribe its hardware queue slots: every process may open up to
-    GPU_MAX_HW_QUEUES (default 4) queues, the device has about 24 slots for user queues, and beyond them the scheduler
-    time-slices the queues -- runs get 4-5x slower and, rarely, a kernel's results become visible late (DESIGN.md section
-    9 B: measured with and without this setting, profiles/r03_stress_*.log, r03_count_queues.log).  More than five ranks
-    per device therefore run with two queues per process.  One rank per GPU (production) is never touched."""
+    """Hook for ranks that SHARE a GPU.  Measured in round 3: eight processes with the runtime's
+    default of four hardware queues each can push the device into time-slicing its queues (4-5x slower, rarely a wrong
+    result in a kernel of ANY kind); GPU_MAX_HW_QUEUES=2 made the 8-rank stress and the complete 8-rank reference matrix
+    clean -- but one full-suite run with it hung in an 8-rank sweep, so it is NOT applied by default.  The library keeps
+    its own stream count at two per process on shared devices instead; set CUDECOMP_TEST_SHARED_GPU_QUEUES=N to try a
+    queue limit for runs with more than five ranks per device."""
+    want = os.environ.get("CUDECOMP_TEST_SHARED_GPU_QUEUES")
+    if not want:
+        return
     ngpu = max(gpus_on_this_host(), 1)
-    per_gpu = (nranks + ngpu - 1) // ngpu
-    if per_gpu > 5:
-        env.setdefault("GPU_MAX_HW_QUEUES", "2")
+    if (nranks + ngpu - 1) // ngpu > 5:
+        env.setdefault("GPU_MAX_HW_QUEUES", want)
 
 
 def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_rank_env=None):
