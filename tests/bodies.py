@@ -86,6 +86,64 @@ def run_moves(moves, n, bufs):
         dst[...] = src.copy()
 
 
+def stage_of_move(m, axis, k, K):
+    """python twin of csrc/plan.cc stageOfMove: range k of K of the move's extent along global axis `axis`"""
+    r = cd.ExtMove()
+    for f in ("src_buf", "dst_buf", "src_off", "dst_off", "peer", "reserved"):
+        setattr(r, f, getattr(m, f))
+    n = m.extent[axis]
+    lo, hi = n * k // K, n * (k + 1) // K
+    for i in range(3):
+        r.extent[i], r.ss[i], r.ds[i] = m.extent[i], m.ss[i], m.ds[i]
+    r.extent[axis] = hi - lo
+    r.src_off = m.src_off + lo * m.ss[axis]
+    r.dst_off = m.dst_off + lo * m.ds[axis]
+    return r
+
+
+def staged_exchange_gloo(plan, bufs, stages, rank, itemsize, dt):
+    """The staged pipeline of the one-sided pipelined transports (csrc/transport.cc peerStagedExchange) with a real
+    multi-process exchange: all pack stages, then per stage the contiguous sub-chunks travel over gloo and the stage's
+    range of every source is unpacked.  The receive area is poisoned first."""
+    import torch
+    import torch.distributed as dist
+    P, K = plan.nranks, max(1, min(stages, plan.stage_limit))
+    sendb, recvb = bufs[plan.send_buf], bufs[plan.recv_buf]
+    if plan.recv_buf == 2:
+        lo = plan.recv_base + min(plan.recv_off[i] for i in range(P))
+        hi = plan.recv_base + max(plan.recv_off[i] + plan.recv_cnt[i] for i in range(P))
+        recvb[lo:hi] = -12345
+    for k in range(K):
+        moves = (cd.ExtMove * max(plan.n_pack, 1))(*[stage_of_move(plan.pack[i], plan.stage_axis, k, K) for i in range(plan.n_pack)])
+        run_moves(moves, plan.n_pack, bufs)
+    for k in range(K):
+        reqs, stage = [], {}
+        for d in range(P):
+            gr = plan.member_global_rank[d]
+            n_s, n_r = plan.send_n[d], plan.recv_n[d]
+            per_s, per_r = plan.send_cnt[d] // n_s, plan.recv_cnt[d] // n_r
+            so = plan.send_base + plan.send_off[d] + (n_s * k // K) * per_s
+            sc = (n_s * (k + 1) // K - n_s * k // K) * per_s
+            ro = plan.recv_base + plan.recv_off[d] + (n_r * k // K) * per_r
+            rc = (n_r * (k + 1) // K - n_r * k // K) * per_r
+            if gr == rank:
+                assert sc == rc
+                recvb[ro:ro + rc] = sendb[so:so + sc].copy()
+                continue
+            s = torch.from_numpy(np.ascontiguousarray(sendb[so:so + sc]).view(np.uint8).copy())
+            stage[d] = (torch.zeros(rc * itemsize, dtype=torch.uint8), ro, rc)
+            if sc:
+                reqs.append(dist.isend(s, gr))
+            if rc:
+                reqs.append(dist.irecv(stage[d][0], gr))
+        for q in reqs:
+            q.wait()
+        for d, (t, ro, rc) in stage.items():
+            recvb[ro:ro + rc] = t.numpy().view(dt)
+        moves = (cd.ExtMove * max(plan.n_unpack, 1))(*[stage_of_move(plan.unpack[i], plan.stage_axis, k, K) for i in range(plan.n_unpack)])
+        run_moves(moves, plan.n_unpack, bufs)
+
+
 def plan_transpose_gloo(rank, nranks, args):
     """Execute the product's transpose plans with numpy + gloo send/recv and check them against the analytic
     oracle, for a full X->Y->Z->Y->X chain (tests/cc/transpose_test.cc:516-559)."""
@@ -119,7 +177,10 @@ def plan_transpose_gloo(rank, nranks, args):
                 plan = cd.cudecompExtGetTransposePlan(h, gd, op, halos[ai], halos[ao], pads[ai], pads[ao],
                                                       inplace=not oop, backend_override=backend)
                 bufs = [cur, nxt, work]
-                if not plan.noop:
+                staged = args.get("stages", 0) > 1 and backend in (cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_MPI_P2P_PL)
+                if not plan.noop and plan.exchange and staged:
+                    staged_exchange_gloo(plan, bufs, args["stages"], rank, a.itemsize, dt)
+                elif not plan.noop:
                     run_moves(plan.pack, plan.n_pack, bufs)
                     if plan.exchange:
                         P = plan.nranks

@@ -48,3 +48,18 @@ def test_synthetic_host_groups(nranks, pdims, hosts):
     env = [{"CUDECOMP_HOSTNAME_OVERRIDE": "node-" + h} for h in hosts]
     for failures in run_ranks(nranks, "tests.bodies", "plan_transpose_gloo", args, per_rank_env=env):
         assert failures == []
+
+
+@pytest.mark.parametrize("nranks,pdims,stages", [(2, (2, 1), 2), (2, (1, 2), 3), (4, (2, 2), 2), (4, (1, 4), 4), (3, (1, 3), 3)])
+def test_staged_pipeline_over_gloo(nranks, pdims, stages):
+    """The staged pipeline of the one-sided pipelined transports (NVSHMEM_PL / MPI_P2P_PL enums) on 2-4 processes: the
+    product's plan is cut into stages exactly as csrc/transport.cc does, the contiguous sub-chunks of each stage travel
+    over gloo, and each stage's range is unpacked from a poisoned receive area; every hop of the cycle is compared with
+    the analytic oracle, in and out of place, halos and padding included."""
+    for ac, halos, pads in (((1, 1, 1), None, None), ((0, 0, 0), [K.IN_HALO, K.OUT_HALO, K.IN_HALO], [K.IN_PAD, K.OUT_PAD, K.IN_PAD])):
+        args = {"gdims": (12, 10, 14), "pdims": pdims, "ac": ac, "kind": 1, "stages": stages,
+                "backends": [cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_MPI_P2P_PL]}
+        if halos:
+            args.update({"halos": halos, "pads": pads})
+        for failures in run_ranks(nranks, "tests.bodies", "plan_transpose_gloo", args):
+            assert failures == []

@@ -130,20 +130,7 @@ def test_transpose_cycle_returns_the_input(d, inplace, symmetric):
         simulate_transpose(d, op, zero, zero, inplace, False, symmetric, 0)
 
 
-def _stage_of(m, axis, k, K):
-    """python twin of csrc/plan.cc stageOfMove: range k of K of the move's extent along global axis `axis`"""
-    r = cd.ExtMove()
-    C_fields = ("src_buf", "dst_buf", "src_off", "dst_off", "peer", "reserved")
-    for f in C_fields:
-        setattr(r, f, getattr(m, f))
-    n = m.extent[axis]
-    lo, hi = n * k // K, n * (k + 1) // K
-    for i in range(3):
-        r.extent[i], r.ss[i], r.ds[i] = m.extent[i], m.ss[i], m.ds[i]
-    r.extent[axis] = hi - lo
-    r.src_off = m.src_off + lo * m.ss[axis]
-    r.dst_off = m.dst_off + lo * m.ds[axis]
-    return r
+from tests.bodies import stage_of_move as _stage_of  # noqa: E402
 
 
 def simulate_staged_transpose(d, op, halos, pads, inplace, stages, npergroup):
