@@ -1123,9 +1123,10 @@ void peerReadyGate(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan
   CD_CHECK_HIP(hipEventRecord(pc.copyEvent(2 * P), stream));  // "go": receivers ready
 }
 
-// All chunks at once: they are packed (caller), then P-1 concurrent copies,
-// one stream per peer so that every link / SDMA queue is busy, each gated by the receiver's ready flag; `stream`
-// continues when every incoming chunk has landed and every outgoing copy is done (the send area may be reused).
+// All chunks at once: they are packed (caller), the receivers' ready flags are awaited once on `stream`, then the P-1
+// chunks travel concurrently -- copy engines: one hipMemcpyAsync per peer on a stream of its own (every link / SDMA
+// queue busy); kernel copies: ONE launch on one extra stream whose workgroups serve the destinations round robin.
+// `stream` continues when every incoming chunk has landed and every outgoing copy is done (the send area may be reused).
 void peerAlltoall(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePlan& p, const ExchangeBuffers& b, int es,
                   const PeerCall& call, hipStream_t stream) {
   PeerContext& pc = peerOf(h, ci);

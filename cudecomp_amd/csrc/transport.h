@@ -8,9 +8,12 @@
 //         686-707.
 //   PEER  (NVSHMEM* enums; also the MPI_* enums when the library is built without MPI): one-sided copies
 //         over xGMI into the receiver's IPC-mapped buffer.  Every pair of GPUs owns a dedicated link, so
-//         the P-1 copies of an all-to-all are issued at once, each on its own stream/SDMA queue.
-//         Ordered ON THE STREAM by epoch flags in a host-pinned board shared by the ranks of the node (sync.hip):
-//         no call blocks the host on GPU work, and the sequence can be captured into a hipGraph.
+//         the P-1 copies of an all-to-all are issued at once (copy engines: each on its own stream / SDMA queue;
+//         kernel copies: one launch that feeds every link); the pipelined enums run a staged pipeline with all peers
+//         in every stage.  Ordered ON THE STREAM by monotonic flags (call * 16 + step) in a host-pinned board shared
+//         by the ranks of the node, or -- opt-in -- in device memory of the poller (sync.hip): no call blocks the
+//         host on GPU work, and the sequence can be captured into a hipGraph.  Buffers from cudecompMalloc are pooled
+//         with their mappings, and new mappings are verified by page tags.
 //         Replaces the reference's NVSHMEM put path (comm_routines.h:122-258) and stands in for
 //         CUDA-aware MPI (comm_routines.h:325-413).  Needs the written buffer to be visible to the peer:
 //         buffers from cudecompMalloc are mapped once at allocation (NVSHMEM enums require them, as the

@@ -137,7 +137,8 @@ cudecompResult_t cudecompExtPeerProbe(cudecompHandle_t handle, void* buffer, siz
  * graphs_captured / graph_launches -- CUDECOMP_ENABLE_CUDA_GRAPHS: distinct pack loops captured, graph launches;
  * local -- no exchange; rccl, mpi -- those transports; peer_barrier -- one-sided exchange, all chunks at once (the
  * name dates from the host-barrier implementation; it is ordered by device-side flags now);
- * peer_fused -- fused pack+put (NVSHMEM_SM); peer_pipelined -- per-peer pipeline with pairwise flags. */
+ * peer_fused -- fused pack+put (NVSHMEM_SM); peer_pipelined -- staged pipeline of the one-sided
+ * transport (all peers in every stage). */
 typedef struct {
   int64_t graphs_captured, graph_launches;
   int64_t local, rccl, mpi, peer_barrier, peer_fused, peer_pipelined;
