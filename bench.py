@@ -213,7 +213,7 @@ def cpu_baseline_mpi(sample, size, layout):
             pr *= 2
         pc = ranks // pr
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        warm, timed = 1, 3
+        warm, timed = 2, 5  # (about 32 s at 1024^3 on 64 cores: the first cycle after start-up runs 20-30 % slow)
         t0 = time.perf_counter()
         out = subprocess.run([mpirun, "-np", str(ranks), exe, str(sample), str(pr), str(pc),
                               "1" if layout == "contiguous" else "0", str(warm), str(timed)], env=env, capture_output=True,
@@ -237,6 +237,8 @@ def cpu_baseline_mpi(sample, size, layout):
             except Exception as e1:
                 config1["%dx%d" % grid] = "unavailable: %s" % str(e1)[:80]
         return {"value": round(rec["gbps"], 4), "unit": "GB/s", "cores": ranks, "kind": "port",
+                "cycle_s": {"avg": round(rec["cycle_s"], 4), "min": round(rec.get("cycle_s_min", rec["cycle_s"]), 4),
+                            "max": round(rec.get("cycle_s_max", rec["cycle_s"]), 4), "std": round(rec.get("cycle_s_std", 0.0), 4)},
                 "config1_256cube_fp32_2_ranks": dict(config1, what="BASELINE.json configs[0]: 256^3 fp32 slab, 2-rank host-MPI "
                                                      "a2a CPU path (oracle pack/unpack + MPI_Alltoallv), 3 warm-up + 5 timed cycles"),
                 "sample": "%d^3 fp64 X->Y->Z->Y->X cycle on host memory (%s), %d MPI ranks (%dx%d grid, one per core; MPICH "
