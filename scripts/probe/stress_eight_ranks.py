@@ -16,6 +16,12 @@ from tests.mp import run_binary_ranks  # noqa: E402
 from tests.test_gpu_native import _binary  # noqa: E402
 from tests.test_gpu_native_sweep import _mem_orders, _tcase  # noqa: E402
 
+if os.environ.get("STRESS_PARENT_CONTEXT"):
+    # a NINTH process with a live GPU context, as the pytest process of the suite has once it ran a test in-process
+    import torch
+    _keep = torch.zeros(1 << 20, device="cuda")
+    _keep += 1
+    torch.cuda.synchronize()
 backend, iters = (0 if sys.argv[1] == "mix" else int(sys.argv[1])), int(sys.argv[2])
 env = dict(a.split("=", 1) for a in sys.argv[3:])
 env.setdefault("CUDECOMP_VERBOSE", "1")
@@ -50,5 +56,5 @@ for it in range(iters):
         for l in text.splitlines():
             if "CUDECOMP:VERIFY" in l:
                 print("iteration %d (passed) %s" % (it, l.strip()[-260:]), flush=True)
-print("backend %d env %s: %d of %d iterations failed (%d cases each, %.0f s); stale IPC mappings detected and replaced: %d"
-      % (backend, env, bad, iters, len(lines), time.time() - t0, stale), flush=True)
+print("parent holds a GPU context: %s; backend %d env %s: %d of %d iterations failed (%d cases each, %.0f s); stale IPC mappings detected and replaced: %d"
+      % (bool(os.environ.get("STRESS_PARENT_CONTEXT")), backend, env, bad, iters, len(lines), time.time() - t0, stale), flush=True)
