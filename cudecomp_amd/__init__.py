@@ -98,7 +98,7 @@ class ExtHaloPlan(C.Structure):
 class ExtCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("graphs_captured", "graph_launches", "local", "rccl", "mpi", "peer_barrier",
                                           "peer_fused", "peer_pipelined", "direct_puts", "workspace_pool_hits",
-                                          "stale_ipc_mappings")]
+                                          "stale_ipc_mappings", "workspace_pool_bytes", "retired_imports")]
 
 
 class ExtLinkInfo(C.Structure):
@@ -126,7 +126,7 @@ EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecom
                "cudecompExtGetTransposeTimings", "cudecompExtGetHaloTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
                "cudecompExtPlanTranspose", "cudecompExtPlanHalo", "cudecompExtPencilInfo", "cudecompExtShiftedRank",
                "cudecompExtWorkspaceSizes", "cudecompExtGetLinkInfo", "cudecompExtLastKernelName",
-               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs"]
+               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs", "cudecompExtTrimWorkspacePool"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -193,6 +193,7 @@ def lib():
         L.cudecompExtGetHaloTimings.argtypes = [vp, vp, i32, i32, C.POINTER(ExtTransposeTimings)]
         L.cudecompExtPeerProbe.argtypes = [vp, vp, C.c_size_t, pi32]
         L.cudecompExtGetCounters.argtypes = [vp, vp, C.POINTER(ExtCounters)]
+        L.cudecompExtTrimWorkspacePool.argtypes = [vp]
         L.cudecompExtPlanTranspose.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, pi32, pi32, C.c_bool, i32,
                                                i32, i32, C.POINTER(ExtTransposePlan)]
         L.cudecompExtPencilInfo.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, C.POINTER(PencilInfo)]
@@ -420,6 +421,11 @@ def cudecompExtWorkspaceSizes(grid, rank, axis, halo_extents):
     _check(lib().cudecompExtWorkspaceSizes(C.byref(grid), rank, axis, _i3(halo_extents), C.byref(t), C.byref(h)),
            "cudecompExtWorkspaceSizes")
     return t.value, h.value
+
+
+def cudecompExtTrimWorkspacePool(handle):
+    """Really release what cudecompFree has parked in the workspace pool (collective)."""
+    _check(lib().cudecompExtTrimWorkspacePool(handle), "cudecompExtTrimWorkspacePool")
 
 
 def cudecompExtGetCounters(handle, gd):

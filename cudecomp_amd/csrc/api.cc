@@ -385,8 +385,8 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     if (const char* v = std::getenv("CUDECOMP_PIPELINE_MIN_STAGE_MIB")) h->pipeline_min_stage_bytes = std::strtoll(v, nullptr, 10) << 20;
     if (const char* v = std::getenv("CUDECOMP_PIPELINE_STAGES")) {
       const long k = std::strtol(v, nullptr, 10);
-      if (k >= 1 && k <= 15) h->pipeline_stages = (int)k;
-      else if (h->rank == 0) printf("CUDECOMP:WARN: Invalid CUDECOMP_PIPELINE_STAGES value (%s); expected 1..15.\n", v);
+      if (k >= 1 && k <= 14) h->pipeline_stages = (int)k;  // (flags carry call * 16 + step: steps 1..14 are stages, 15 = done)
+      else if (h->rank == 0) printf("CUDECOMP:WARN: Invalid CUDECOMP_PIPELINE_STAGES value (%s); expected 1..14.\n", v);
     }
     if (const char* v = std::getenv("CUDECOMP_PEER_TIMEOUT")) {
       const double t = std::strtod(v, nullptr);
@@ -410,6 +410,11 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     if (const char* v = std::getenv("CUDECOMP_WINDOW_STORES")) h->tuning.window_mode = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
     if (const char* v = std::getenv("CUDECOMP_WINDOW_WIDE")) h->tuning.window_wide = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
     if (const char* v = std::getenv("CUDECOMP_TILE_WALK")) h->tuning.walk_order = (int)std::strtol(v, nullptr, 10);  // tuning aid
+    if (const char* v = std::getenv("CUDECOMP_XCD_WALK")) h->tuning.xcd_walk = (int)std::strtol(v, nullptr, 10);  // diagnostic
+    if (const char* v = std::getenv("CUDECOMP_LOCAL_STORE_POLICY")) {  // diagnostic: cached | stream | writethrough
+      const std::string e(v);
+      h->tuning.local_store_policy = e == "cached" ? 0 : (e == "stream" ? 1 : (e == "writethrough" ? 2 : -1));
+    }
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))
       if (std::strtol(v, nullptr, 10) == 1) h->tuning.force_class = MOVE_GENERIC;
 
@@ -590,6 +595,8 @@ cudecompResult_t cudecompGridDescDestroy(cudecompHandle_t handle, cudecompGridDe
     delete grid_desc;  // (drains the device if the descriptor ran one-sided exchanges)
     // the LAST exchange of a descriptor has no later call that would report a wait kernel that gave up: do it here
     if (one_sided) peerCheckStatus(handle);
+    // mappings of user buffers their owners have re-created since are kept open on purpose (transport.cc map()); bound them
+    peerTrimRetiredImports(handle, 32);
   }
   CD_API_CATCH()
   return CUDECOMP_RESULT_SUCCESS;

@@ -34,6 +34,7 @@ class Error : public std::exception {
 #define CD_NOT_SUPPORTED(detail) CD_THROW(CUDECOMP_RESULT_NOT_SUPPORTED, "Not supported.", detail)
 #define CD_INTERNAL_ERROR(detail) CD_THROW(CUDECOMP_RESULT_INTERNAL_ERROR, "Internal error.", detail)
 #define CD_BOOTSTRAP_ERROR(detail) CD_THROW(CUDECOMP_RESULT_MPI_ERROR, "MPI error.", detail)
+#define CD_HIP_ERROR(detail) CD_THROW(CUDECOMP_RESULT_CUDA_ERROR, "CUDA error.", detail)
 #define CD_PEER_ERROR(detail) CD_THROW(CUDECOMP_RESULT_NVSHMEM_ERROR, "NVSHMEM error.", detail)
 
 #define CD_CHECK_HIP(expr)                                                                         \

@@ -327,7 +327,19 @@ cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDes
     out->peer_fused = gd->path_count[PATH_PEER_FUSED];
     out->peer_pipelined = gd->path_count[PATH_PEER_PIPELINED];
     out->direct_puts = gd->direct_puts;
-    peerPoolCounters(handle, &out->workspace_pool_hits, &out->stale_ipc_mappings);
+    peerPoolCounters(handle, &out->workspace_pool_hits, &out->stale_ipc_mappings, &out->workspace_pool_bytes, &out->retired_imports);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtTrimWorkspacePool(cudecompHandle_t handle) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    workspaceTrimPool(handle);
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {

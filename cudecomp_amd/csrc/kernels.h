@@ -31,6 +31,10 @@ struct KernelTuning {
   int interleave_rows = 1;         // batched row copies: workgroups serve the moves round robin (0: one move after the other)
   int window_wide = 0;             // window kernel, 8-byte elements: 1 = 128 x 64 tiles with 512 threads (CUDECOMP_WINDOW_WIDE=1)
   int window_mode = -1;            // transposes onto rows off the 64-byte grid: -1 window kernel for moves >= 1 MiB, 0 never, 1 always
+  int local_store_policy = -1;     // diagnostic (CUDECOMP_LOCAL_STORE_POLICY): stores of LOCAL moves 0 cached, 1 non-temporal,
+                                   // 2 system-scope write-through + wait at the end of the kernel (as remote stores); -1 by size
+  int xcd_walk = 1;                // diagnostic (CUDECOMP_XCD_WALK=0): transposes deal tiles round robin instead of one
+                                   // contiguous run of tiles per XCD
 };
 
 // Execute `n` independent moves (disjoint destinations) of `es`-byte elements.  bufs[BufId] are the

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const Batch b) {
   // fp64 permutations: 2.73 -> 2.66 ms strided-read side, 3.02 -> 2.93 ms strided-write side).
   const unsigned int nb = b.first_block[mi + 1] - b.first_block[mi];
   unsigned int lt = lb;
-  if (b.p1[mi]) {
+  if (b.p1[mi] & 1) {
     const unsigned int per = nb >> 3;
     if (lb < (per << 3)) lt = (lb & 7u) * per + (lb >> 3);
   }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(NT) void transpose_window_kernel(const Batch b) {
   const unsigned int ti_n = b.t0[mi], tj_n = b.t1[mi];
   const unsigned int nb = b.first_block[mi + 1] - b.first_block[mi];
   unsigned int lt = lb;
-  if (b.p1[mi]) {  // XCD-contiguous walk, see transpose_kernel
+  if (b.p1[mi] & 1) {  // XCD-contiguous walk, see transpose_kernel
     const unsigned int per = nb >> 3;
     if (lb < (per << 3)) lt = (lb & 7u) * per + (lb >> 3);
   }
@@ -644,6 +644,11 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
   c.elements = m.elements();
   c.stream = ((c.elements * es >= kStreamBytes || (tuning && tuning->force_streaming)) && !(tuning && tuning->no_streaming)) ? 2 : 0;
   if (remote) c.stream = 3;  // destination in a peer's memory: write-through stores, whatever the size
+  // diagnostic override of the store policy of local moves (the 8-shared-rank hunt)
+  const int local_policy = (tuning && !remote) ? tuning->local_store_policy : -1;
+  if (local_policy == 0) c.stream = 0;
+  else if (local_policy == 1) c.stream = 2;
+  else if (local_policy == 2) c.stream = 3;
   c.dm.src = static_cast<const char*>(bufs[m.src_buf]) + m.src_off * es;
   c.dm.dst = static_cast<char*>(dst_base ? dst_base : bufs[m.dst_buf]) + m.dst_off * es;
   const bool force_generic = tuning && tuning->force_class == MOVE_GENERIC;
@@ -701,7 +706,7 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     int vw = 16 / es;
     if (c.dm.e[0] % vw != 0 || c.dm.e[1] % vw != 0) vw = 1;
     c.variant = vw;
-    c.p1 = 1;  // XCD-contiguous tile walk
+    c.p1 = (tuning && tuning->xcd_walk == 0) ? 0 : 1;  // XCD-contiguous tile walk
     c.swizzle = (tuning && tuning->lds_swizzle >= 0) ? tuning->lds_swizzle != 0 : es != 16;
     // Tile walk order inside an XCD's run: j first makes consecutive tiles extend the same DESTINATION rows
     // (contiguous write stream per row), i first the same source rows.  Measured on 8 GiB permutations
@@ -738,6 +743,8 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     // 4- and 8-byte elements with the same padding prefer streaming, profiles/r02_tuning.md).
     if (es == 16 && c.stream == 2 && !c.window && c.dm.e[2] > 1 && ((uintptr_t)(c.dm.ds[2] * es) % 4096) != 0) c.stream = 0;
     if (tuning && tuning->stream_mode >= 0 && c.stream != 3 && c.stream != 0) c.stream = tuning->stream_mode;
+    if (local_policy == 0) c.stream = 0;
+    else if (local_policy == 1 && c.stream == 0) c.stream = 2;
     if (tuning && tuning->walk_order >= 0) j_first = tuning->walk_order == 1;
     if (j_first) c.p1 |= 2;
     // (window kernel, 4-byte elements: 64 x 128 tiles -- a 64-byte unit is 16 elements, the longer window halves the

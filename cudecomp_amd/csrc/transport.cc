@@ -177,8 +177,13 @@ class PeerContext {
     mine.seed = ((unsigned long long)mine.pid << 32) ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^
                 ((unsigned long long)next_region_id_ << 20);
     if (verify_mappings_ && error.empty()) {
-      launchTagPages(base, bytes, mine.seed, nullptr);
-      if (hipDeviceSynchronize() != hipSuccess) {
+      bool launched = true;
+      try {
+        launchTagPages(base, bytes, mine.seed, nullptr);
+      } catch (const Error&) {  // a local launch failure is agreed on below like every other failure
+        launched = false;
+      }
+      if (!launched || hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
         error = "stamping the page tags of a new workspace failed";
         mine.bytes = 0;
@@ -219,8 +224,13 @@ class PeerContext {
         if (p == h_->rank || !r.peer_base[p]) continue;
         unsigned long long bad = 0;
         if (hipMemcpy(verify_count_, &bad, sizeof(bad), hipMemcpyHostToDevice) != hipSuccess) break;
-        launchCheckPages(r.peer_base[p], (size_t)all[p].bytes, all[p].seed, verify_count_, nullptr);
-        if (hipMemcpy(&bad, verify_count_, sizeof(bad), hipMemcpyDeviceToHost) != hipSuccess) {
+        bool launched = true;
+        try {
+          launchCheckPages(r.peer_base[p], (size_t)all[p].bytes, all[p].seed, verify_count_, nullptr);
+        } catch (const Error&) {
+          launched = false;
+        }
+        if (!launched || hipMemcpy(&bad, verify_count_, sizeof(bad), hipMemcpyDeviceToHost) != hipSuccess) {
           (void)hipGetLastError();
           bad = 1;
         }
@@ -322,6 +332,26 @@ class PeerContext {
     return evict;
   }
   bool poolEnabled() const { return pool_limit_ > 0; }
+  // The pools and their eviction lists must be identical on every rank (park / take decisions involve collectives): the
+  // limit each rank derived from ITS device (or environment) is replaced by the smallest one.  Collective; called once,
+  // when the transport comes up, before any park or take.
+  void agreePoolLimit() {
+    const int64_t mine = (int64_t)std::min<size_t>(pool_limit_, (size_t)1 << 62);
+    pool_limit_ = (size_t)(-h_->boot->allreduceMaxI64(-mine));
+  }
+  size_t poolBytes() const { return pool_bytes_; }
+  // Retired mappings of re-created user buffers (see map()) each keep the exporter's FREED memory referenced: keep the
+  // newest `keep`, close the older ones.  Called where every rank has drained its device and nothing is being imported
+  // (grid descriptor destruction), never right before an import -- that is the sequence section 9 A warns about.
+  void trimRetiredImports(size_t keep) {
+    if (retired_imports_.size() <= keep) return;
+    (void)hipDeviceSynchronize();  // nothing this rank enqueued may still be copying through them
+    const size_t n = retired_imports_.size() - keep;
+    for (size_t i = 0; i < n; ++i) (void)hipIpcCloseMemHandle(retired_imports_[i]);
+    (void)hipGetLastError();
+    retired_imports_.erase(retired_imports_.begin(), retired_imports_.begin() + n);
+  }
+  size_t retiredImports() const { return retired_imports_.size(); }
   std::vector<void*> drainPool() {
     std::vector<void*> all;
     for (auto& p : pool_) all.push_back(p.base);
@@ -751,9 +781,15 @@ class PeerContext {
 
 uint64_t peerSlotHigh(cudecompHandle_t h, int slot) { return h->peer ? h->peer->slotHigh(slot) : 0; }
 
-void peerPoolCounters(cudecompHandle_t h, int64_t* pool_hits, int64_t* stale_mappings) {
+void peerPoolCounters(cudecompHandle_t h, int64_t* pool_hits, int64_t* stale_mappings, int64_t* pool_bytes, int64_t* retired) {
   *pool_hits = h->peer ? h->peer->poolHits() : 0;
   *stale_mappings = h->peer ? h->peer->staleMappingsSeen() : 0;
+  if (pool_bytes) *pool_bytes = h->peer ? (int64_t)h->peer->poolBytes() : 0;
+  if (retired) *retired = h->peer ? (int64_t)h->peer->retiredImports() : 0;
+}
+
+void peerTrimRetiredImports(cudecompHandle_t h, size_t keep) {
+  if (h->peer) h->peer->trimRetiredImports(keep);
 }
 
 void peerCheckStatus(cudecompHandle_t h) {
@@ -916,10 +952,18 @@ void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
     } catch (const Error&) {
       have_dev = false;
     }
+    h->peer->agreePoolLimit();
     if (!h->boot->allreduceOr(!have_dev)) h->peer->setupDeviceFlags();  // (geometry-only jobs have no device)
     peerMeasureLink(h);
   }
 }
+
+namespace {
+void releaseRegionForReal(cudecompHandle_t h, void* ptr) {
+  h->peer->unregisterRegion(ptr);
+  CD_CHECK_HIP(hipFree(ptr));
+}
+}  // namespace
 
 void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
   void* ptr = nullptr;
@@ -933,11 +977,45 @@ void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
     // hipIpcOpenMemHandle with the mapping of a predecessor of the allocation (freed, re-created at the same address,
     // DESIGN.md section 9); such a buffer is set aside -- so that the next attempt gets another address -- and
     // released once a good one is registered.
-    std::vector<void*> set_aside;
+    // Buffers whose mappings turned out stale are SET ASIDE -- so that the next attempt gets another address -- and
+    // released as soon as a later candidate exists (at most one is alive beside the candidate: peak 2x the request) or
+    // on any exit, also an exceptional one.
+    struct SetAside {
+      std::vector<void*> bufs;
+      ~SetAside() {
+        for (void* q : bufs) (void)hipFree(q);
+      }
+      void keepOnlyLatest() {
+        while (bufs.size() > 1) {
+          (void)hipFree(bufs.front());
+          bufs.erase(bufs.begin());
+        }
+      }
+    } set_aside;
     std::string failure;
+    bool drained = false;
     for (int attempt = 0; attempt < 4 && !ptr; ++attempt) {
       void* cand = nullptr;
-      CD_CHECK_HIP(hipMalloc(&cand, bytes));
+      // A failing hipMalloc is AGREED ON before anybody acts on it (a rank that threw on its own would leave the others
+      // in registerRegion's collectives).  First remedy: everything the pool has parked is released -- collectively, the
+      // pools are identical on every rank -- and the allocation is tried again.
+      hipError_t me = hipMalloc(&cand, bytes);
+      if (me != hipSuccess) {
+        (void)hipGetLastError();
+        cand = nullptr;
+      }
+      if (h->boot->allreduceOr(cand == nullptr)) {
+        if (cand) (void)hipFree(cand);
+        if (!drained) {
+          drained = true;
+          for (void* q : h->peer->drainPool()) releaseRegionForReal(h, q);
+          --attempt;  // the retry after draining does not count as a mapping attempt
+          continue;
+        }
+        CD_HIP_ERROR(std::string("cudecompMalloc: hipMalloc of ") + std::to_string(bytes) + " bytes failed on " +
+                     (me != hipSuccess ? "this rank" : "another rank") + " (out of memory), also after releasing the workspace pool");
+      }
+      set_aside.keepOnlyLatest();
       bool stale = false;
       try {
         if (h->peer->registerRegion(cand, bytes, &stale)) ptr = cand;
@@ -947,18 +1025,17 @@ void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
         // another address gets its chance before the library gives up on sharing the workspace.
         failure = e.what();
       }
-      if (!ptr) set_aside.push_back(cand);
+      if (!ptr) set_aside.bufs.push_back(cand);
     }
     if (!ptr) {
       // not shared: still a valid workspace for the RCCL / MPI transports; an operation that needs the one-sided
       // transport will report the IPC problem itself
       if (failure.empty()) failure = "every attempt to map the workspace into the other ranks ended with a stale mapping";
-      ptr = set_aside.back();
-      set_aside.pop_back();
+      ptr = set_aside.bufs.back();
+      set_aside.bufs.pop_back();
     } else {
       failure.clear();
     }
-    for (void* q : set_aside) (void)hipFree(q);
     if (!failure.empty()) {
       if (h->rank == 0 && !h->ipc_warned) {
         fprintf(stderr, "CUDECOMP:WARN: workspace could not be shared over IPC (%s); one-sided (NVSHMEM*/default MPI*) "
@@ -972,12 +1049,11 @@ void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable) {
   return ptr;
 }
 
-namespace {
-void releaseRegionForReal(cudecompHandle_t h, void* ptr) {
-  h->peer->unregisterRegion(ptr);
-  CD_CHECK_HIP(hipFree(ptr));
+void workspaceTrimPool(cudecompHandle_t h) {
+  if (!h->peer) return;
+  CD_CHECK_HIP(hipDeviceSynchronize());
+  for (void* q : h->peer->drainPool()) releaseRegionForReal(h, q);
 }
-}  // namespace
 
 void workspaceFreeRaw(cudecompHandle_t h, void* ptr) {
   if (h->peer) {

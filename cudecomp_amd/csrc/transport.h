@@ -36,7 +36,8 @@ void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer);
 // highest counter value found in row `slot` of the shared board that involves this rank (0 without a board)
 uint64_t peerSlotHigh(cudecompHandle_t h, int slot);
 // cudecompMalloc calls served from the pool of released workspaces / new IPC mappings found stale (0, 0 without a peer transport)
-void peerPoolCounters(cudecompHandle_t h, int64_t* pool_hits, int64_t* stale_mappings);
+void peerPoolCounters(cudecompHandle_t h, int64_t* pool_hits, int64_t* stale_mappings, int64_t* pool_bytes = nullptr,
+                      int64_t* retired_imports = nullptr);
 // throws if a device-side wait of an earlier one-sided exchange gave up (dead peer)
 void peerCheckStatus(cudecompHandle_t h);
 // one-direction copy rate to the next rank through both copy engines (collective; fills h->link_gbps_*)
@@ -49,6 +50,10 @@ void* workspaceAlloc(cudecompHandle_t h, cudecompGridDesc_t gd, size_t bytes);  
 // same, without a grid descriptor: peer_capable = map the buffer into the other ranks for one-sided writes
 void* workspaceAllocRaw(cudecompHandle_t h, size_t bytes, bool peer_capable);
 void workspaceFreeRaw(cudecompHandle_t h, void* ptr);
+// collective: really release everything cudecompFree has parked in the workspace pool (cudecompExtTrimWorkspacePool)
+void workspaceTrimPool(cudecompHandle_t h);
+// mappings of re-created user buffers that are kept open (see PeerContext::map): close all but the newest `keep`
+void peerTrimRetiredImports(cudecompHandle_t h, size_t keep);
 void workspaceFree(cudecompHandle_t h, cudecompGridDesc_t gd, void* ptr);       // collective
 
 struct ExchangeBuffers {

@@ -146,9 +146,19 @@ typedef struct {
   /* per HANDLE (not per descriptor): cudecompMalloc calls served from the pool of released workspaces, and new IPC
    * mappings whose page tags did not read back (stale mapping: the workspace was re-created at another address) */
   int64_t workspace_pool_hits, stale_ipc_mappings;
+  /* per HANDLE: bytes cudecompFree has parked in the workspace pool right now; IPC mappings of re-created user buffers
+   * that are kept open (the newest 32 survive a cudecompGridDescDestroy) */
+  int64_t workspace_pool_bytes, retired_imports;
 } cudecompExtCounters_t;
 cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
                                         cudecompExtCounters_t* counters);
+
+/* cudecompFree PARKS workspaces of the one-sided transports (allocation and peer mappings stay; the next cudecompMalloc
+ * of a fitting size reuses them): up to min(1/8 of the device memory, 32 GiB) per handle -- the smallest such limit
+ * over all ranks; CUDECOMP_WORKSPACE_POOL_MIB overrides it, 0 = park nothing -- until cudecompFinalize.  A
+ * cudecompMalloc that runs out of memory releases the pool by itself and retries; an APPLICATION that needs the memory
+ * for its own allocations calls this.  Collective over the handle's communicator. */
+cudecompResult_t cudecompExtTrimWorkspacePool(cudecompHandle_t handle);
 
 /* One-direction copy rate from this rank to the next rank of the node, measured when the one-sided transport came up
  * (64 MiB, both engines, slowest rank): gbps_sdma through hipMemcpyAsync (copy engines), gbps_cu through the library's

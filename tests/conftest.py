@@ -13,6 +13,11 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
+    os.environ["CUDECOMP_PYTEST_MAIN_PID"] = str(os.getpid())
+    _pytest_sessionstart_build(session)
+
+
+def _pytest_sessionstart_build(session):
     """A fresh checkout has no binaries (they are git-ignored): build the product library before the first test
     needs it.  hipcc cross-compiles gfx950 without a GPU; with everything built this is a no-op `make`.  The product
     itself never builds or falls back on its own -- cudecomp_amd.lib() raises if the library is missing."""
@@ -29,17 +34,123 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-# Test modules that use the GPU IN THE PYTEST PROCESS (everything else launches its ranks as child processes).
-_INPROCESS_GPU_MODULES = ("test_gpu_autotune", "test_gpu_halo", "test_gpu_kernels", "test_gpu_transpose", "test_gpu_multi_device")
+# ---- tests that use the GPU in the process that runs them ------------------------------------------------------------
+# Most GPU tests only LAUNCH ranks (tests/mp.py).  The modules below also call the library from the test function
+# itself.  If the pytest process did that, it would hold a GPU context for the rest of the session and be a NINTH
+# process on the device whenever an 8-rank case runs: nine processes are more than one MI355X has address-space slots
+# (VMIDs) for, the kernel driver then time-slices ALL processes (4-5x slower) and -- measured, DESIGN.md section 9 --
+# about one case in a few thousand comes back wrong in that regime, whatever the order of the tests.  So the pytest
+# process never opens the GPU: consecutive tests of these modules run in a forked child (one child per run of such
+# tests, so the HIP start-up is paid once per module, not per test) whose reports are replayed here; the child is gone
+# before the next rank-launching test starts.  Round 3 ordered the suite around the problem instead
+# (pytest_collection_modifyitems); that hook is gone.  CUDECOMP_TEST_NO_FORK=1 runs everything in this process.
+_INPROCESS_GPU_MODULES = ("test_gpu_autotune", "test_gpu_halo", "test_gpu_kernels", "test_gpu_transpose",
+                          "test_inprocess_isolation")
 
 
-def pytest_collection_modifyitems(config, items):
-    """Run the tests that only LAUNCH ranks before the ones that touch the GPU in this process.  Once the pytest process
-    holds a GPU context of its own it is a NINTH process on the device while an 8-rank case runs, and nine processes on
-    one MI355X are more than the device can give an address-space slot (VMID) each: measured in round 3
-    (profiles/r03_stress_ninth_process.log), eight ranks plus such a parent fail about one case in
-    a few thousand, eight ranks alone do not.  The order inside each group is unchanged."""
-    def late(item):
-        name = os.path.basename(str(item.fspath))
-        return any(name.startswith(m) for m in _INPROCESS_GPU_MODULES)
-    items.sort(key=late)  # stable
+def _inprocess(item):
+    name = os.path.basename(str(item.fspath))
+    return any(name.startswith(m) for m in _INPROCESS_GPU_MODULES)
+
+
+class _Child:
+    """A forked copy of the pytest process that runs the items it is told to and sends their reports back."""
+
+    def __init__(self, session):
+        import pickle
+        self.pickle = pickle
+        self.session = session
+        c2p_r, c2p_w = os.pipe()
+        p2c_r, p2c_w = os.pipe()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        self.pid = os.fork()
+        if self.pid == 0:
+            os.close(c2p_r)
+            os.close(p2c_w)
+            self._serve(os.fdopen(p2c_r, "rb"), os.fdopen(c2p_w, "wb"))
+            os._exit(0)
+        os.close(c2p_w)
+        os.close(p2c_r)
+        self.rx, self.tx = os.fdopen(c2p_r, "rb"), os.fdopen(p2c_w, "wb")
+
+    def _serve(self, rx, tx):
+        from _pytest.runner import runtestprotocol
+        items = self.session.items
+        try:
+            while True:
+                try:
+                    index, next_index = self.pickle.load(rx)
+                except EOFError:
+                    break
+                item = items[index]
+                nextitem = items[next_index] if next_index is not None else None
+                reports = runtestprotocol(item, nextitem=nextitem, log=False)
+                data = [item.config.hook.pytest_report_to_serializable(config=item.config, report=r) for r in reports]
+                self.pickle.dump(data, tx)
+                tx.flush()
+                if nextitem is None:
+                    break
+        finally:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+
+    def run(self, index, next_index):
+        """Reports of item `index`, or None if the child died while running it."""
+        try:
+            self.pickle.dump((index, next_index), self.tx)
+            self.tx.flush()
+            return self.pickle.load(self.rx)
+        except (EOFError, BrokenPipeError, OSError):
+            return None
+
+    def close(self):
+        for f in (self.tx, self.rx):
+            try:
+                f.close()
+            except OSError:
+                pass
+        try:
+            _, status = os.waitpid(self.pid, 0)
+        except ChildProcessError:
+            status = 0
+        return status
+
+
+_child = [None]
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_runtest_protocol(item, nextitem):
+    if not _inprocess(item) or not hasattr(os, "fork") or os.environ.get("CUDECOMP_TEST_NO_FORK"):
+        return None
+    from _pytest.reports import TestReport
+    session = item.session
+    index = session.items.index(item)
+    keep = nextitem is not None and _inprocess(nextitem)
+    if _child[0] is None:
+        _child[0] = _Child(session)
+    ihook = item.ihook
+    ihook.pytest_runtest_logstart(nodeid=item.nodeid, location=item.location)
+    data = _child[0].run(index, session.items.index(nextitem) if keep else None)
+    if data is None:
+        status = _child[0].close()
+        _child[0] = None
+        reports = [TestReport(nodeid=item.nodeid, location=item.location, keywords={}, outcome="failed", when="call",
+                              longrepr="the forked GPU child died while running this test (wait status %d)" % status)]
+    else:
+        reports = [item.config.hook.pytest_report_from_serializable(config=item.config, data=d) for d in data]
+        if not keep:
+            _child[0].close()
+            _child[0] = None
+    for rep in reports:
+        ihook.pytest_runtest_logreport(report=rep)
+    ihook.pytest_runtest_logfinish(nodeid=item.nodeid, location=item.location)
+    return True
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _child[0] is not None:
+        _child[0].close()
+        _child[0] = None

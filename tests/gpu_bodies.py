@@ -438,64 +438,60 @@ def absent_peer(rank, nranks, args):
     return out
 
 
-def halo_sampled(rank, nranks, args):
-    """Halo update at a size where building the full expected array on the host is too slow: initialise the
-    interior on the device with the global linear index, update dims 0,1,2, then check a strided sample of
-    ALL cells (halo cells included) against the periodic closed form computed with numpy."""
+def halo_exact(rank, nranks, args):
+    """Halo update checked in EVERY cell at any size (reference: tests/ctest/halo_tests.cc:229-272 compares the whole
+    pencil): the interior is initialised on the device with the global linear index (-1 elsewhere), dims 0, 1, 2 are
+    updated, and the whole halo-carrying pencil is compared on the device with its closed form -- the global coordinate of
+    every cell wrapped modulo the global extent for periodic dims, -1 where a non-periodic domain ends."""
     h, gd, g = _setup(rank, nranks, args)
     halo, periods = args["halo"], args["periods"]
     gdims = args["gdims"]
     failures = []
+
+    def bc(vec, m):  # memory position m varies fastest for m = 0: [shape2, shape1, shape0] tensors by broadcasting
+        view = [1, 1, 1]
+        view[2 - m] = -1
+        return vec.view(view)
+
     for axis in args.get("axes", [0]):
         p = cd.cudecompGetPencilInfo(h, gd, axis, halo)
         shape, lo, order = list(p.shape), list(p.lo), list(p.order)
-        # device-side fill: value = global linear index of the (wrapped) cell for interior cells, -1 elsewhere
+        pos = {order[m]: m for m in range(3)}
         idx = [torch.arange(shape[m], device="cuda", dtype=torch.int64) for m in range(3)]
-        gcoord = [None] * 3
-        interior = [None] * 3
+        gcoord, interior, wrapped, valid = [None] * 3, [None] * 3, [None] * 3, [None] * 3
         for m in range(3):
             ax = order[m]
             gcoord[ax] = idx[m] + lo[m] - halo[ax]
             interior[ax] = (idx[m] >= halo[ax]) & (idx[m] < shape[m] - halo[ax])
-        # memory position m varies fastest for m = 0: build [shape2, shape1, shape0] tensors by broadcasting
-        def bc(vec, m):
-            view = [1, 1, 1]
-            view[2 - m] = -1
-            return vec.view(view)
-        pos = {order[m]: m for m in range(3)}
-        val = (bc(gcoord[0], pos[0]) + gdims[0] * (bc(gcoord[1], pos[1]) + gdims[1] * bc(gcoord[2], pos[2])))
-        inside = bc(interior[0], pos[0]) & bc(interior[1], pos[1]) & bc(interior[2], pos[2])
-        data = torch.where(inside, val.to(torch.float64), torch.full((), -1.0, dtype=torch.float64, device="cuda")).contiguous()
-        del val, inside
+            outside = (gcoord[ax] < 0) | (gcoord[ax] >= gdims[ax])
+            wrapped[ax] = torch.remainder(gcoord[ax], gdims[ax]) if periods[ax] else gcoord[ax]
+            valid[ax] = torch.ones_like(outside) if periods[ax] else ~outside
+        minus1 = torch.full((), -1.0, dtype=torch.float64, device="cuda")
+
+        def build(coord, mask):
+            val = bc(coord[0], pos[0]) + gdims[0] * (bc(coord[1], pos[1]) + gdims[1] * bc(coord[2], pos[2]))
+            ok = bc(mask[0], pos[0]) & bc(mask[1], pos[1]) & bc(mask[2], pos[2])
+            return torch.where(ok, val.to(torch.float64), minus1).contiguous()
+
+        data = build(gcoord, interior)
         wsz = max(cd.cudecompGetHaloWorkspaceSize(h, gd, axis, halo), 1)
         work = cd.cudecompMalloc(h, gd, wsz * 8)
         for dim in range(3):
             cd.cudecompUpdateHalos(axis, h, gd, data.data_ptr(), work, cd.DOUBLE, halo, periods, dim, None, G.stream_ptr())
         torch.cuda.synchronize()
-        flat = data.view(-1)
-        sample = torch.arange(rank, flat.numel(), args.get("sample", 100003), device="cuda")
-        got = flat[sample].cpu().numpy()
-        s = sample.cpu().numpy()
-        l = [s % shape[0], s // shape[0] % shape[1], s // (shape[0] * shape[1])]
-        gl = [None] * 3
-        unset = np.zeros(len(s), dtype=bool)
-        for m in range(3):
-            ax = order[m]
-            c = l[m] + lo[m] - halo[ax]
-            out = (c < 0) | (c >= gdims[ax])
-            if periods[ax]:
-                c = np.mod(c, gdims[ax])
-            else:
-                unset |= out
-            gl[ax] = c
-        exp = (gl[0] + gdims[0] * (gl[1] + gdims[1] * gl[2])).astype(np.float64)
-        exp[unset] = -1.0
-        bad = np.nonzero(got != exp)[0]
-        if len(bad):
-            failures.append("rank %d axis %d: %d of %d sampled cells differ (first at %d: exp %r got %r)"
-                            % (rank, axis, len(bad), len(s), s[bad[0]], exp[bad[0]], got[bad[0]]))
+        exp = build(wrapped, valid)
+        if args.get("check_closed_form_against_oracle"):  # small grids: the closed form itself vs the oracle's reference
+            ref = g.fill_halo_reference(g.pencil_info(rank, axis, halo), 1, periods)
+            if not np.array_equal(exp.view(-1).cpu().numpy(), ref):
+                failures.append("rank %d axis %d: the device-side closed form differs from the oracle" % (rank, axis))
+        if not torch.equal(data, exp):
+            ne = (data != exp).view(-1)
+            first = int(ne.nonzero()[0])
+            failures.append("rank %d axis %d: %d of %d cells differ (first at %d: expected %r, got %r)"
+                            % (rank, axis, int(ne.sum()), ne.numel(), first, float(exp.view(-1)[first]), float(data.view(-1)[first])))
+            del ne
         cd.cudecompFree(h, gd, work)
-        del data
+        del data, exp
         torch.cuda.empty_cache()
     cd.cudecompGridDescDestroy(h, gd)
     return failures

@@ -80,6 +80,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     if (bad) {
       fprintf(stderr, "rank %d: %lld cells differ after the halo updates\n", rank, (long long)bad);
       ++failures;
+      diagnoseMismatch("halo", data, host, ref, &init, p, false);
     }
   } catch (...) {
     if (data) (void)hipFree(data);

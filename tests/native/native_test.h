@@ -201,6 +201,144 @@ inline int64_t countMismatches(const std::vector<elem_t>& got, const std::vector
   return bad;
 }
 
+// ---- failure diagnostics (the 8-shared-rank hunt) -------------------------------------------------
+// When a result differs, say WHAT the wrong cells hold and WHO can see the right ones, so that one failing case tells
+// "stores late" from "stores lost" from "stores visible through one XCD only":
+//   1. classify the wrong cells of the first read: sentinel (CUDECOMP_TEST_SENTINEL=1 pre-fills out-of-place outputs),
+//      the buffer's previous content, -1, anything else; index range;
+//   2. read again with hipMemcpy 1 ms later (late vs lost);
+//   3. read the pencil with a KERNEL, eight passes, pass x using only the workgroups that run on XCD x (workgroup b runs on
+//      XCD b % 8; HW_REG_XCC_ID is recorded to check that), into pinned host memory: a result that only one XCD can see sits
+//      in that XCD's L2 or behind that XCD's address translation;
+//   4. read a third time with hipMemcpy: the end of the reader kernels wrote every L2 back, so data that was merely
+//      parked in an L2 is in memory now, data behind a stale translation is not.
+__global__ void diag_read_k(const elem_t* src, elem_t* dst, long long n, int xcd, unsigned int* xcc_seen) {
+  if ((int)(blockIdx.x % 8) != xcd) return;
+  if (threadIdx.x == 0) {
+    const unsigned int id = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xfu;  // HW_REG_XCC_ID[3:0]
+    atomicOr(xcc_seen, 1u << id);
+  }
+  const long long nb = gridDim.x / 8, b = blockIdx.x / 8;
+  for (long long i = b * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) dst[i] = src[i];
+}
+
+inline bool sentinelRequested() {
+  const char* v = std::getenv("CUDECOMP_TEST_SENTINEL");
+  return v && std::atoi(v) != 0;
+}
+inline elem_t sentinelValue() {
+  elem_t e;
+  std::memset(&e, 0xEE, sizeof(e));
+  return e;
+}
+inline bool sameBits(const elem_t& a, const elem_t& b) { return std::memcmp(&a, &b, sizeof(elem_t)) == 0; }
+
+inline void diagnoseMismatch(const char* what, const elem_t* dev, const std::vector<elem_t>& first,
+                             const std::vector<elem_t>& ref, const std::vector<elem_t>* previous,
+                             const cudecompPencilInfo_t& p, bool interior_only) {
+  const int rank = worldRank();
+  const int64_t n = p.size;
+  const elem_t sent = sentinelValue();
+  elem_t minus1;
+  make(minus1, -1.0);
+  auto inside = [&](int64_t idx) {
+    if (!interior_only) return true;
+    int64_t l[3] = {idx % p.shape[0], (idx / p.shape[0]) % p.shape[1], idx / ((int64_t)p.shape[0] * p.shape[1])};
+    for (int k = 0; k < 3; ++k) {
+      const int h = p.halo_extents[p.order[k]];
+      if (l[k] < h || l[k] >= (p.hi[k] - p.lo[k] + 1) + h) return false;
+    }
+    return true;
+  };
+  auto countBad = [&](const std::vector<elem_t>& got) {
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i)
+      if (inside(i) && !(got[i] == ref[i])) ++bad;
+    return bad;
+  };
+  int64_t bad = 0, lo = -1, hi = -1, n_sent = 0, n_prev = 0, n_m1 = 0, runs = 0, last_bad = -2;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!inside(i) || first[i] == ref[i]) continue;
+    ++bad;
+    if (lo < 0) lo = i;
+    hi = i;
+    if (i != last_bad + 1) ++runs;
+    last_bad = i;
+    if (sameBits(first[i], sent)) ++n_sent;
+    else if (previous && (int64_t)previous->size() > i && sameBits(first[i], (*previous)[i])) ++n_prev;
+    else if (sameBits(first[i], minus1)) ++n_m1;
+  }
+  const int64_t plane = (int64_t)p.shape[0] * p.shape[1];
+  fprintf(stderr,
+          "DIAG rank %d %s: %lld wrong cells in [%lld, %lld] (planes %lld..%lld of %d, %lld runs, pencil %d x %d x %d, dev %p): "
+          "%lld hold the sentinel, %lld the buffer's previous content, %lld -1, %lld something else\n",
+          rank, what, (long long)bad, (long long)lo, (long long)hi, (long long)(lo / plane), (long long)(hi / plane), p.shape[2],
+          (long long)runs, p.shape[0], p.shape[1], p.shape[2], (const void*)dev, (long long)n_sent, (long long)n_prev,
+          (long long)n_m1, (long long)(bad - n_sent - n_prev - n_m1));
+  std::vector<elem_t> again(n);
+  std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  if (hipMemcpy(again.data(), dev, n * sizeof(elem_t), hipMemcpyDeviceToHost) != hipSuccess) return;
+  const int64_t bad1 = countBad(again);
+  elem_t* pinned = nullptr;
+  unsigned int* seen = nullptr;
+  long long per_xcd[8];
+  unsigned int seen_mask[8];
+  if (hipHostMalloc((void**)&pinned, n * sizeof(elem_t), hipHostMallocMapped) == hipSuccess &&
+      hipHostMalloc((void**)&seen, 64, hipHostMallocMapped) == hipSuccess) {
+    for (int x = 0; x < 8; ++x) {
+      std::memset(pinned, 0x5a, n * sizeof(elem_t));
+      *seen = 0;
+      diag_read_k<<<8 * 64, 256>>>(dev, pinned, n, x, seen);
+      (void)hipDeviceSynchronize();
+      int64_t b = 0;
+      for (int64_t i = 0; i < n; ++i)
+        if (inside(i) && !(pinned[i] == ref[i])) ++b;
+      per_xcd[x] = b;
+      seen_mask[x] = *seen;
+    }
+    (void)hipHostFree(pinned);
+    (void)hipHostFree(seen);
+  } else {
+    for (int x = 0; x < 8; ++x) per_xcd[x] = -1, seen_mask[x] = 0;
+  }
+  int64_t bad2 = -1;
+  if (hipMemcpy(again.data(), dev, n * sizeof(elem_t), hipMemcpyDeviceToHost) == hipSuccess) bad2 = countBad(again);
+  fprintf(stderr,
+          "DIAG rank %d %s: wrong cells: first read %lld, hipMemcpy 1 ms later %lld, kernel readers on XCD 0..7: %lld %lld %lld %lld "
+          "%lld %lld %lld %lld (XCC_ID masks %x %x %x %x %x %x %x %x), hipMemcpy after the reader kernels %lld\n",
+          rank, what, (long long)bad, (long long)bad1, per_xcd[0], per_xcd[1], per_xcd[2], per_xcd[3], per_xcd[4], per_xcd[5],
+          per_xcd[6], per_xcd[7], seen_mask[0], seen_mask[1], seen_mask[2], seen_mask[3], seen_mask[4], seen_mask[5], seen_mask[6],
+          seen_mask[7], (long long)bad2);
+}
+
+// Data buffers of the test programs: hipMalloc / hipFree per case as the reference's programs do, or -- with
+// CUDECOMP_TEST_REUSE_BUFFERS=1 (an arm of the hunt: does allocation churn matter?) -- grown once and kept for the process.
+struct TestBuffer {
+  static bool reuse() {
+    static const bool r = [] { const char* v = std::getenv("CUDECOMP_TEST_REUSE_BUFFERS"); return v && std::atoi(v) != 0; }();
+    return r;
+  }
+  static elem_t* get(int slot, int64_t nel) {
+    if (!reuse()) {
+      elem_t* q = nullptr;
+      T_CHECK_HIP(hipMalloc((void**)&q, nel * sizeof(elem_t)));
+      return q;
+    }
+    static elem_t* kept[4] = {nullptr, nullptr, nullptr, nullptr};
+    static int64_t cap[4] = {0, 0, 0, 0};
+    if (cap[slot] < nel) {
+      if (kept[slot]) T_CHECK_HIP(hipFree(kept[slot]));
+      const int64_t want = std::max<int64_t>(nel, 1 << 22);
+      T_CHECK_HIP(hipMalloc((void**)&kept[slot], want * sizeof(elem_t)));
+      cap[slot] = want;
+    }
+    return kept[slot];
+  }
+  static void put(elem_t* q) {
+    if (!reuse() && q) T_CHECK_HIP(hipFree(q));
+  }
+};
+
 inline std::vector<std::string> readTestFile(const std::string& path) {
   std::vector<std::string> lines;
   std::ifstream f(path);

@@ -13,6 +13,9 @@
 //   -m                       data buffers from cudecompMalloc instead of hipMalloc (the reference's -m selects managed
 //                            memory, which has no counterpart here; with NVSHMEM_SM such buffers take the direct put)
 //   -f|--testfile FILE       one case per line
+// Environment (diagnostics of the shared-GPU hunt, see native_test.h): CUDECOMP_TEST_SENTINEL=1 pre-fills every out-of-place
+// output with 0xEE bytes; CUDECOMP_TEST_REUSE_BUFFERS=1 keeps the data buffers for the whole process; a failing hop always
+// prints two DIAG lines (what the wrong cells hold, who can see the right ones).
 #include "native_test.h"
 
 static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
@@ -65,8 +68,8 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
       T_CHECK_CD(cudecompMalloc(handle, gdesc, (void**)&data, nel * sizeof(elem_t)));
       if (oop) T_CHECK_CD(cudecompMalloc(handle, gdesc, (void**)&data2, nel * sizeof(elem_t)));
     } else {
-      T_CHECK_HIP(hipMalloc((void**)&data, nel * sizeof(elem_t)));
-      if (oop) T_CHECK_HIP(hipMalloc((void**)&data2, nel * sizeof(elem_t)));
+      data = TestBuffer::get(0, nel);
+      if (oop) data2 = TestBuffer::get(1, nel);
     }
     T_CHECK_CD(cudecompMalloc(handle, gdesc, (void**)&work, std::max<int64_t>(ws, 1) * sizeof(elem_t)));
 
@@ -84,17 +87,26 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     const Hop hops[4] = {{"XToY", cudecompTransposeXToY, 0, 1}, {"YToZ", cudecompTransposeYToZ, 1, 2},
                          {"ZToY", cudecompTransposeZToY, 2, 1}, {"YToX", cudecompTransposeYToX, 1, 0}};
     elem_t *in = data, *out = oop ? data2 : data;
+    const bool sentinel = oop && sentinelRequested();
+    int hop_index = 0;
     for (const Hop& h : hops) {
+      if (sentinel) T_CHECK_HIP(hipMemset(out, 0xEE, p[h.to].size * sizeof(elem_t)));
       T_CHECK_CD(h.fn(handle, gdesc, in, out, work, kDtype, halo[h.from].data(), halo[h.to].data(), pad[h.from].data(),
                       pad[h.to].data(), 0));
       T_CHECK_HIP(hipDeviceSynchronize());
+      if (hop_index == 0 && rank == worldSize() - 1 && std::getenv("CUDECOMP_TEST_INJECT_FAULT"))  // exercises the DIAG path
+        T_CHECK_HIP(hipMemset(out + p[h.to].size / 2, 0xEE, std::min<int64_t>(1000, p[h.to].size / 2) * sizeof(elem_t)));
       host.resize(p[h.to].size);
       T_CHECK_HIP(hipMemcpy(host.data(), out, p[h.to].size * sizeof(elem_t), hipMemcpyDeviceToHost));
       const int64_t bad = countMismatches(host, ref[h.to], p[h.to], true);
       if (bad) {
         fprintf(stderr, "rank %d: %s: %lld interior cells differ\n", rank, h.name, (long long)bad);
         ++failures;
+        // what `out` held before this hop (out of place, no sentinel): the pencil written two hops earlier
+        const std::vector<elem_t>* previous = (oop && !sentinel && hop_index >= 1) ? &ref[hops[hop_index - 1].from] : nullptr;
+        diagnoseMismatch(h.name, out, host, ref[h.to], previous, p[h.to], true);
       }
+      ++hop_index;
       if (oop) std::swap(in, out);
     }
   } catch (...) {
@@ -103,8 +115,8 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
       if (data2) (void)cudecompFree(handle, gdesc, data2);
       data = data2 = nullptr;
     }
-    if (data) (void)hipFree(data);
-    if (data2) (void)hipFree(data2);
+    if (data && !TestBuffer::reuse()) (void)hipFree(data);
+    if (data2 && !TestBuffer::reuse()) (void)hipFree(data2);
     if (work) (void)cudecompFree(handle, gdesc, work);
     (void)cudecompGridDescDestroy(handle, gdesc);
     throw;
@@ -113,8 +125,8 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     T_CHECK_CD(cudecompFree(handle, gdesc, data));
     if (data2) T_CHECK_CD(cudecompFree(handle, gdesc, data2));
   } else {
-    T_CHECK_HIP(hipFree(data));
-    if (data2) T_CHECK_HIP(hipFree(data2));
+    TestBuffer::put(data);
+    TestBuffer::put(data2);
   }
   T_CHECK_CD(cudecompFree(handle, gdesc, work));
   T_CHECK_CD(cudecompGridDescDestroy(handle, gdesc));

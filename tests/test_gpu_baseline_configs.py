@@ -107,18 +107,19 @@ def test_config3_autotuned_process_grid_at_full_size():
 
 @pytest.mark.parametrize("axes,backend,env", [([0, 1, 2], cd.HALO_COMM_MPI, {}),
                                               ([0, 1, 2], cd.HALO_COMM_NVSHMEM, {}),
-                                              ([0, 2], cd.HALO_COMM_NCCL, {"CUDECOMP_FORCE_HALO_OVERLAP": "1"})],
-                         ids=["mpi_xyz", "nvshmem_xyz", "rccl_overlapped_xz"])
+                                              ([0, 1, 2], cd.HALO_COMM_NCCL, {"CUDECOMP_FORCE_HALO_OVERLAP": "1"})],
+                         ids=["mpi_xyz", "nvshmem_xyz", "rccl_overlapped_xyz"])
 def test_config5_halo_full_size(axes, backend, env):
     # C5: 2048 x 2048 x 1024 fp64, 2x4, halo width 2, periodic: UpdateHalos{X,Y,Z} dims 0,1,2 with pack / exchange /
-    # unpack overlapped; verified on a strided sample of ALL cells against the closed form (interior initialised with
-    # the global linear index).  The RCCL variant (two send/recv groups on a side stream) runs through the stand-in.
+    # unpack overlapped; EVERY cell of every halo-carrying pencil (4.4 GB per rank) is compared on the device with the
+    # closed form (reference: tests/ctest/halo_tests.cc:229-272 compares whole pencils; nothing is sampled here either).
+    # The RCCL variant (two send/recv groups on a side stream) runs through the stand-in.
     env = dict(env)
     if backend == cd.HALO_COMM_NCCL:
         if not os.path.exists(SHIM):
             pytest.skip("tests/shim/libfake_rccl.so not built")
         env["CUDECOMP_TEST_RCCL_SHIM"] = SHIM
     args = {"gdims": (2048, 2048, 1024), "pdims": (2, 4), "kind": 1, "halo": (2, 2, 2), "periods": (1, 1, 1),
-            "axes": axes, "halo_backend": backend, "sample": 200003}
-    for failures in run_ranks(8, "tests.gpu_bodies", "halo_sampled", args, timeout=900, extra_env=env):
+            "axes": axes, "halo_backend": backend}
+    for failures in run_ranks(8, "tests.gpu_bodies", "halo_exact", args, timeout=900, extra_env=env):
         assert failures == []

@@ -35,3 +35,15 @@ def test_ctest_halo_cases_multi_rank_peer_transport():
                  "args": dict(c, axes=[c["axis"]], halo_backend=cd.HALO_COMM_MPI)} for c in cases]
         for failures in run_ranks(n, "tests.gpu_bodies", "many", {"jobs": jobs}, timeout=600):
             assert failures == []
+
+
+@pytest.mark.parametrize("pdims", [(2, 2), (1, 4), (4, 1)], ids=lambda p: "%dx%d" % p)
+def test_every_cell_closed_form_matches_the_oracle(pdims):
+    """The device-side closed form that checks config 5 in every cell (gpu_bodies.halo_exact) against the oracle's
+    restatement of the reference's analytic halo oracle on a small ragged grid, mixed periodicity, both layouts."""
+    jobs = [{"fn": "halo_exact", "id": "ac%d_%s" % (ac, "".join(map(str, per))),
+             "args": {"gdims": (21, 18, 26), "pdims": pdims, "kind": 1, "halo": (2, 1, 3), "periods": per, "axes": [0, 1, 2],
+                      "ac": (ac, ac, ac), "halo_backend": cd.HALO_COMM_MPI, "check_closed_form_against_oracle": True}}
+            for ac in (0, 1) for per in ((1, 1, 1), (1, 0, 1), (0, 0, 0))]
+    for failures in run_ranks(4, "tests.gpu_bodies", "many", {"jobs": jobs}, timeout=600):
+        assert failures == []
