@@ -16,7 +16,8 @@ AND in place.  Rank 0 prints ONE JSON line.
   cpu_baseline the host-MPI CPU path (oracle/cpu_mpi_cycle: the oracle's pack / unpack around MPI_Alltoallv, one rank
                per core) on the same workload, rank 0, N = 1 only
   extra        N = 1 only: BASELINE config 4 (1024^3 complex<fp32> 3-D FFT forward + inverse, benchmark/fft3d_benchmark)
-               and config 5 (halo update of its per-rank pencil), measured after the timed region
+               and config 5 (halo update of its per-rank pencil), measured after the timed region; `dtypes`: the cycle at
+               8-GiB pencils for fp32 / complex64 / complex128, both layouts, per-hop kernel and roofline fraction
   N > 1        the fixed 1024^3 problem on N ranks ("strong"); first over RCCL (process grid autotuned), then -- after
                a preflight that tries every one-sided transport on a small grid and reports pass/fail per transport
                to stderr -- with the library's autotuner choosing among all transports that passed; the faster valid
@@ -186,13 +187,45 @@ def cpu_baseline(sample, size, layout):
         a, b = b, a
     dt = time.perf_counter() - t0
     return {"value": round(4 * n * 8 / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "ranks": 1, "grid": [1, 1], "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "mpi_version": None,
+            "pinning": "none (single process)", "sample_edge": sample,
             "sample": "%d^3 fp64 X->Y->Z->Y->X cycle (%s of the benchmark's volume), 1x1 grid, %s layout, out-of-place, "
                       "one cycle, %.1f s on one core" % (sample, "all" if sample == size else "1/%d" % (size // sample) ** 3,
                                                          layout, dt)}
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def run_cpu_mpi_cycle(mpirun, exe, env, ranks, grid, n, contiguous, warm, timed, kind=1, timeout=300):
+    """One launch of oracle/cpu_mpi_cycle with the ranks bound to cores; the record it prints, plus the wall time."""
+    import subprocess
+    t0 = time.perf_counter()
+    cmd = [mpirun, "-bind-to", "core", "-np", str(ranks), exe, str(n), str(grid[0]), str(grid[1]), "1" if contiguous else "0",
+           str(warm), str(timed), str(kind)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    rec["wall_s"] = time.perf_counter() - t0
+    return rec
+
+
+def cycle_stats(rec, scale=1.0, digits=4):
+    return {"avg": round(rec["cycle_s"] * scale, digits), "min": round(rec.get("cycle_s_min", rec["cycle_s"]) * scale, digits),
+            "max": round(rec.get("cycle_s_max", rec["cycle_s"]) * scale, digits), "std": round(rec.get("cycle_s_std", 0.0) * scale, digits)}
+
+
 def cpu_baseline_mpi(sample, size, layout):
-    """mpirun -np R oracle/cpu_mpi_cycle ... ; None if there is no MPI here or anything goes wrong."""
+    """mpirun -np R oracle/cpu_mpi_cycle ... ; None if there is no MPI here or anything goes wrong.  Two records of the same
+    workload: one rank per host core (up to 64; `value`) and -- BASELINE.md section 3 -- one rank per GPU SLOT of the node
+    the 8-GPU configuration runs on (8 ranks, 2x4 grid, config 3's decomposition), both with the ranks bound to cores."""
     import shutil
     import subprocess
     try:
@@ -213,37 +246,48 @@ def cpu_baseline_mpi(sample, size, layout):
             pr *= 2
         pc = ranks // pr
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        contiguous = layout == "contiguous"
         warm, timed = 2, 5  # (about 32 s at 1024^3 on 64 cores: the first cycle after start-up runs 20-30 % slow)
-        t0 = time.perf_counter()
-        out = subprocess.run([mpirun, "-np", str(ranks), exe, str(sample), str(pr), str(pc),
-                              "1" if layout == "contiguous" else "0", str(warm), str(timed)], env=env, capture_output=True,
-                             text=True, timeout=300)
-        dt = time.perf_counter() - t0
-        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        rec = run_cpu_mpi_cycle(mpirun, exe, env, ranks, (pr, pc), sample, contiguous, warm, timed)
         if not rec["round_trip_ok"]:
             return None
         frac = "the benchmark's own size" if sample == size else "1/%d of the benchmark's volume" % (size // sample) ** 3
+        # one rank per GPU slot (8 ranks, 2x4): a cycle takes several times longer, so 1 warm-up + 2 timed cycles
+        slots = None
+        if cores >= 8:
+            try:
+                r8 = run_cpu_mpi_cycle(mpirun, exe, env, 8, (2, 4), sample, contiguous, 1, 2, timeout=400)
+                slots = {"value": round(r8["gbps"], 4), "unit": "GB/s", "ranks": 8, "grid": [2, 4], "cores": 8,
+                         "cycle_s": cycle_stats(r8), "warmup": 1, "timed": 2, "sample_edge": sample,
+                         "distinct_cores": r8.get("distinct_cpus"), "bytes_per_rank": r8.get("bytes_per_rank"),
+                         "round_trip_ok": r8["round_trip_ok"], "wall_s": round(r8["wall_s"], 1),
+                         "what": "the same %d^3 fp64 cycle with ONE host-MPI rank per GPU slot of the 8-GPU node "
+                                 "(BASELINE.md section 3): 8 ranks, config 3's 2x4 grid" % sample}
+            except Exception as e8:
+                slots = {"unavailable": str(e8)[:120]}
         # BASELINE config 1 at its own shape: 256^3 fp32 slab decomposition on 2 host-MPI ranks, 3 + 5 cycles (< 1 s)
         config1 = {}
         for grid in ((2, 1), (1, 2)):
             try:
-                o1 = subprocess.run([mpirun, "-np", "2", exe, "256", str(grid[0]), str(grid[1]), "0", "3", "5", "0"], env=env,
-                                    capture_output=True, text=True, timeout=120)
-                r1 = json.loads([l for l in o1.stdout.splitlines() if l.startswith("{")][-1])
-                config1["%dx%d" % grid] = {"GBps": round(r1["gbps"], 3), "cycle_ms": {
-                    "avg": round(r1["cycle_s"] * 1e3, 3), "min": round(r1["cycle_s_min"] * 1e3, 3),
-                    "max": round(r1["cycle_s_max"] * 1e3, 3), "std": round(r1["cycle_s_std"] * 1e3, 3)},
-                    "round_trip_ok": r1["round_trip_ok"]}
+                r1 = run_cpu_mpi_cycle(mpirun, exe, env, 2, grid, 256, False, 3, 5, kind=0, timeout=120)
+                config1["%dx%d" % grid] = {"GBps": round(r1["gbps"], 3), "cycle_ms": cycle_stats(r1, 1e3, 3),
+                                           "round_trip_ok": r1["round_trip_ok"]}
             except Exception as e1:
                 config1["%dx%d" % grid] = "unavailable: %s" % str(e1)[:80]
         return {"value": round(rec["gbps"], 4), "unit": "GB/s", "cores": ranks, "kind": "port",
-                "cycle_s": {"avg": round(rec["cycle_s"], 4), "min": round(rec.get("cycle_s_min", rec["cycle_s"]), 4),
-                            "max": round(rec.get("cycle_s_max", rec["cycle_s"]), 4), "std": round(rec.get("cycle_s_std", 0.0), 4)},
+                # provenance as structured keys (CPU model, core count, MPI version next to the number)
+                "ranks": ranks, "grid": [pr, pc], "cpu_model": cpu_model(), "host_cores": cores,
+                "mpi_version": rec.get("mpi_version"), "pinning": "mpirun -bind-to core",
+                "distinct_cores": rec.get("distinct_cpus"), "bytes_per_rank": rec.get("bytes_per_rank"),
+                "sample_edge": sample, "warmup": warm, "timed": timed,
+                "cycle_s": cycle_stats(rec),
+                "one_rank_per_gpu_slot": slots,
                 "config1_256cube_fp32_2_ranks": dict(config1, what="BASELINE.json configs[0]: 256^3 fp32 slab, 2-rank host-MPI "
                                                      "a2a CPU path (oracle pack/unpack + MPI_Alltoallv), 3 warm-up + 5 timed cycles"),
-                "sample": "%d^3 fp64 X->Y->Z->Y->X cycle on host memory (%s), %d MPI ranks (%dx%d grid, one per core; MPICH "
+                "sample": "%d^3 fp64 X->Y->Z->Y->X cycle on host memory (%s), %d MPI ranks (%dx%d grid, one per core, bound; %s "
                           "shared-memory MPI_Alltoallv), %s layout, out-of-place, %.3f s per cycle, %d warm-up + %d timed "
-                          "cycles, %.1f s in total" % (sample, frac, ranks, pr, pc, layout, rec["cycle_s"], warm, timed, dt)}
+                          "cycles, %.1f s in total" % (sample, frac, ranks, pr, pc, rec.get("mpi_version", "MPI"), layout,
+                                                       rec["cycle_s"], warm, timed, rec["wall_s"])}
     except Exception as e:  # the baseline is a courtesy number: never let it take the benchmark down
         sys.stderr.write("bench.py: host-MPI CPU baseline unavailable (%s); using the single-core oracle\n" % e)
         return None
@@ -391,6 +435,61 @@ def extras_single_gpu(cd, torch, h, stream):
     return out
 
 
+def dtype_table(cd, torch, h, stream):
+    """The other three element types the reference instantiates (src/cudecomp_kernels.cu:29-46; its published sweeps
+    are float and double) at the benchmark's pencil size: 8-GiB pencils on a 1x1 grid, out of place, both layouts,
+    2 warm-up + 5 timed cycles with HIP events around every transpose.  Per hop: ms, achieved GB/s = 2 x pencil bytes / ms,
+    fraction of the 8 TB/s HBM peak and the kernel the library launched for it."""
+    rows = []
+    cases = [("fp32", cd.FLOAT, 4, (2048, 1024, 1024)), ("complex64", cd.FLOAT_COMPLEX, 8, (1024, 1024, 1024)),
+             ("complex128", cd.DOUBLE_COMPLEX, 16, (1024, 1024, 512))]
+    for name, dt, es, gdims in cases:
+        for layout, ac in (("contiguous", (1, 1, 1)), ("default", (0, 0, 0))):
+            row = {"dtype": name, "element_bytes": es, "gdims": list(gdims), "layout": layout}
+            try:
+                gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims, (1, 1), axis_contiguous=ac))
+                nbytes = gdims[0] * gdims[1] * gdims[2] * es
+                gen = torch.Generator(device="cuda")
+                gen.manual_seed(77)
+                a = torch.randint(-2**62, 2**62, (nbytes // 8,), dtype=torch.int64, device="cuda", generator=gen)
+                keep = a.clone()
+                b = torch.zeros_like(a)
+                work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * es)
+                ms = {op: [] for op in cd.OPS}
+                kernels = {}
+                for it in range(2 + 5):
+                    cur, nxt = a, b
+                    for op in cd.OPS:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, dt, stream=stream)
+                        e1.record()
+                        kernels[op] = cd.cudecompExtLastKernelName()
+                        torch.cuda.synchronize()
+                        if it >= 2:
+                            ms[op].append(e0.elapsed_time(e1))
+                        cur, nxt = nxt, cur
+                row["round_trip_ok"] = bool(torch.equal(a, keep))
+                per_op = []
+                for op in cd.OPS:
+                    avg = sum(ms[op]) / len(ms[op])
+                    gbps = 2 * nbytes / (avg * 1e-3) / 1e9
+                    per_op.append({"op": op, "ms": round(avg, 4), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                                   "kernel": kernels[op]})
+                row["per_op"] = per_op
+                row["cycle_ms"] = round(sum(o["ms"] for o in per_op), 4)
+                row["min_frac"] = min(o["frac"] for o in per_op)
+                del a, b, keep
+                cd.cudecompFree(h, gd, work)
+                cd.cudecompGridDescDestroy(h, gd)
+                torch.cuda.empty_cache()
+            except Exception as e:
+                row["error"] = str(e)[:200]
+            rows.append(row)
+    return {"workload": "X->Y->Z->Y->X cycle of an 8-GiB pencil per element type, 1x1 grid, out of place, 2 warm-up + 5 timed "
+                        "cycles, HIP events around every transpose; frac = 2 x pencil bytes / ms / 8 TB/s", "rows": rows}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 _RESULT_FD = [None]
 
@@ -412,8 +511,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1:
-        # a peer that never shows up must cost seconds, not minutes, per attempt (device-side waits and host rendezvous)
-        os.environ.setdefault("CUDECOMP_PEER_TIMEOUT", "15")
+        # a peer that never shows up must cost a minute, not the library default of two, per attempt (device-side waits, host rendezvous)
+        os.environ.setdefault("CUDECOMP_PEER_TIMEOUT", "60")
         os.environ.setdefault("CUDECOMP_BOOTSTRAP_TIMEOUT", "120")
         # pencils of this benchmark live in cudecompMalloc memory: let the autotuner measure NVSHMEM_SM's direct put
         os.environ.setdefault("CUDECOMP_AUTOTUNE_LIBRARY_BUFFERS", "1")
@@ -647,6 +746,7 @@ def main():
         release(m)
         if not args.no_extras and n == 1024:
             out["extra"] = extras_single_gpu(cd, torch, h, stream)
+            out["extra"]["dtypes"] = dtype_table(cd, torch, h, stream)
         if args.cpu_sample != 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, n, args.layout)
         emit(out)

@@ -8,9 +8,12 @@
  *   mpirun -np R ./cpu_mpi_cycle N prow pcol contiguous(0|1) warmup trials [kind: 0 fp32 | 1 fp64 (default) | 2 c64 | 3 c128]
  * prints one JSON line on rank 0: cycle time (max over ranks, min / max / avg / std over the trials, MPI_Wtime after a
  * barrier as benchmark.cu:503-505, 587-590 times the GPU path) and effective GB/s = 4 * N^3 * element bytes / t.
- * BASELINE config 1 is `mpirun -np 2 ./cpu_mpi_cycle 256 2 1 0 3 5 0` (256^3 fp32 slab, 2 ranks). */
+ * The line also carries the MPI library's version string, how many distinct cores the ranks sit on and the bytes each rank
+ * holds.  BASELINE config 1 is `mpirun -np 2 ./cpu_mpi_cycle 256 2 1 0 3 5 0` (256^3 fp32 slab, 2 ranks). */
+#define _GNU_SOURCE
 #include <math.h>
 #include <mpi.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -122,15 +125,39 @@ int main(int argc, char** argv) {
   int ok = memcmp(ref, a, (size_t)p[0].size * es) == 0, all_ok = 0;
   free(ref);
   MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+  /* provenance (CPU model, cores, MPI version next to the number): the MPI library as it names itself, and
+   * the core every rank sits on now (with `mpirun -bind-to core` these are distinct) */
+  char version[MPI_MAX_LIBRARY_VERSION_STRING] = {0};
+  int vlen = 0;
+  MPI_Get_library_version(version, &vlen);
+  for (int i = 0; version[i]; ++i) {
+    if (version[i] == '\n' || version[i] == '\r') {
+      version[i] = 0; /* first line only */
+      break;
+    }
+    if (version[i] == '"' || version[i] == '\\' || (unsigned char)version[i] < 32) version[i] = ' ';
+  }
+  int my_cpu = sched_getcpu();
+  int* cpus = (int*)malloc(sizeof(int) * (size_t)nranks);
+  MPI_Gather(&my_cpu, 1, MPI_INT, cpus, 1, MPI_INT, 0, MPI_COMM_WORLD);
   if (rank == 0) {
+    int distinct = 0;
+    for (int i = 0; i < nranks; ++i) {
+      int seen = 0;
+      for (int j = 0; j < i; ++j) seen |= cpus[j] == cpus[i];
+      distinct += !seen;
+    }
     const double sec = total / trials;
     const double var = sq / trials - sec * sec;
     printf("{\"n\": %d, \"ranks\": %d, \"pdims\": [%d, %d], \"contiguous\": %d, \"warmup\": %d, \"trials\": %d, "
            "\"element_bytes\": %d, \"cycle_s\": %.6f, \"cycle_s_min\": %.6f, \"cycle_s_max\": %.6f, \"cycle_s_std\": %.6f, "
-           "\"gbps\": %.4f, \"round_trip_ok\": %s}\n",
+           "\"gbps\": %.4f, \"round_trip_ok\": %s, \"mpi_version\": \"%.100s\", \"distinct_cpus\": %d, "
+           "\"bytes_per_rank\": %lld}\n",
            n, nranks, pr, pc, contiguous, warmup, trials, es, sec, tmin, tmax, var > 0 ? sqrt(var) : 0.0,
-           4.0 * n * (double)n * n * es / sec / 1e9, all_ok ? "true" : "false");
+           4.0 * n * (double)n * n * es / sec / 1e9, all_ok ? "true" : "false", version, distinct,
+           (long long)((2 * nel + (ws > 0 ? ws : 1)) * es));
   }
+  free(cpus);
   free(a);
   free(b);
   free(w);

@@ -76,7 +76,7 @@ def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_
         env = dict(os.environ)
         env.update({"RANK": str(r), "WORLD_SIZE": str(nranks), "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port_a), "CUDECOMP_BOOTSTRAP_PORT": str(port_b),
-                    "CUDECOMP_BOOTSTRAP_TIMEOUT": "60", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "HSA_ENABLE_IPC_MODE_LEGACY": "0",
                     "PYTHONPATH": ROOT + os.pathsep + env.get("PYTHONPATH", "")})
         # the staged pipeline of the one-sided transports normally keeps stages above 8 MiB; the tests' small grids must
         # run it with several stages too
@@ -136,7 +136,7 @@ def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
         env = dict(os.environ)
         env.update({"RANK": str(r), "WORLD_SIZE": str(nranks), "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port_a), "CUDECOMP_BOOTSTRAP_PORT": str(port_b),
-                    "CUDECOMP_BOOTSTRAP_TIMEOUT": "60", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "CUDECOMP_TEST_JOB": job})
+                    "HSA_ENABLE_IPC_MODE_LEGACY": "0", "CUDECOMP_TEST_JOB": job})
         env.setdefault("CUDECOMP_PIPELINE_MIN_STAGE_MIB", "0")  # small grids still run several pipeline stages
         shared_device_env(nranks, env)
         if extra_env:

@@ -38,10 +38,16 @@ def test_stats_block():
 
 def test_cpu_baseline_record_has_the_required_fields():
     rec = bench.cpu_baseline(32, 1024, "contiguous")  # a small sample: this is a format check, not a measurement
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample",
+                "cpu_model", "mpi_version", "ranks", "grid", "pinning", "host_cores"):  # provenance as keys
         assert key in rec
+    assert rec["ranks"] == rec["cores"] == rec["grid"][0] * rec["grid"][1] and rec["cpu_model"]
     assert rec["kind"] == "port" and rec["unit"] == "GB/s" and rec["value"] > 0 and rec["cores"] >= 1
     if "config1_256cube_fp32_2_ranks" in rec:  # host MPI present: BASELINE config 1 at its own shape rides along
         c1 = rec["config1_256cube_fp32_2_ranks"]
         assert c1["2x1"]["round_trip_ok"] and c1["1x2"]["round_trip_ok"]
         assert set(rec["cycle_s"]) == {"avg", "min", "max", "std"}
+        assert rec["mpi_version"] and rec["pinning"] == "mpirun -bind-to core" and rec["distinct_cores"] >= 1
+        slots = rec["one_rank_per_gpu_slot"]  # one rank per GPU slot, config 3's 2x4 grid
+        if slots is not None and "unavailable" not in slots:
+            assert slots["ranks"] == 8 and slots["grid"] == [2, 4] and slots["round_trip_ok"] and slots["value"] > 0

@@ -33,5 +33,5 @@ def test_calls_return_before_the_gpu_is_done(backend):
 @pytest.mark.parametrize("n,pdims", [(4, (2, 2)), (4, (1, 4)), (2, (2, 1))])
 def test_whole_cycle_in_one_user_graph(backend, n, pdims):
     args = {"gdims": (96, 80, 112), "pdims": pdims, "kind": 1, "ac": (1, 1, 1), "transpose_backend": backend, "replays": 3}
-    for r in run_ranks(n, "tests.gpu_bodies", "graph_cycle", args, timeout=300, extra_env={"CUDECOMP_PEER_TIMEOUT": "30"}):
+    for r in run_ranks(n, "tests.gpu_bodies", "graph_cycle", args, timeout=300):
         assert r["failures"] == []

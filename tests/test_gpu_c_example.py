@@ -63,7 +63,7 @@ def test_transposes_inside_sub_communicators_default_build():
         pytest.skip("no MPI installation")
     native = os.path.join(ROOT, "tests", "native")
     subprocess.check_call(["make", "-s", "-C", native, "build/subcomm_test"])
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SUBCOMM_GROUP="2", SUBCOMM_TRANSPOSE="1", CUDECOMP_PEER_TIMEOUT="30")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SUBCOMM_GROUP="2", SUBCOMM_TRANSPOSE="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([mpirun, "-np", "4", os.path.join(native, "build", "subcomm_test")], env=env,
