@@ -129,6 +129,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     TestBuffer::put(data2);
   }
   T_CHECK_CD(cudecompFree(handle, gdesc, work));
+  notePaths(handle, gdesc);
   T_CHECK_CD(cudecompGridDescDestroy(handle, gdesc));
   return failures ? 1 : 0;
 }
