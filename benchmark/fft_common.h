@@ -44,6 +44,65 @@ __global__ void scale_kernel(C* data, double factor, long long n) {
   }
 }
 
+template <typename R>
+__global__ void scale_real_kernel(R* data, R factor, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) data[i] *= factor;
+}
+
+// FFT over the `rank` FASTEST memory dims of a pencil at once (they must be complete on this rank), batched over the
+// remaining dims: the slab shortcuts of the reference's benchmark (benchmark.cu:340-373: one 2-D FFT instead of two 1-D
+// passes and a transpose when a process-grid dim is 1, one 3-D FFT on a single rank).  `real_x` > 0 selects the
+// real-to-complex flavour (benchmark.cu:238-330): the pencil then is the COMPLEX X pencil, real_x/2+1 long along x (which
+// must be its fastest dim), and the same memory viewed as rows of 2*(real_x/2+1) reals holds the real field in place.
+struct BlockFFT {
+  hipfftHandle fwd = 0, inv = 0;
+  bool real = false, dbl = false;
+
+  void create(const cudecompPencilInfo_t& p, int rank, bool dbl_, int real_x, hipStream_t stream) {
+    dbl = dbl_;
+    real = real_x > 0;
+    int n[3], cdim[3], rdim[3];  // slowest first, as hipFFT wants them
+    long long cdist = 1, batch = 1;
+    for (int i = 0; i < rank; ++i) {
+      const int m = rank - 1 - i;  // memory dim
+      n[i] = cdim[i] = rdim[i] = p.shape[m];
+      cdist *= p.shape[m];
+    }
+    for (int m = rank; m < 3; ++m) batch *= p.shape[m];
+    if (!real) {
+      const hipfftType type = dbl ? HIPFFT_Z2Z : HIPFFT_C2C;
+      CHECK_FFT(hipfftPlanMany(&fwd, rank, n, nullptr, 1, (int)cdist, nullptr, 1, (int)cdist, type, (int)batch));
+      inv = fwd;
+    } else {
+      n[rank - 1] = real_x;               // logical length along x
+      rdim[rank - 1] = 2 * p.shape[0];    // reals per row (padded), complex per row = p.shape[0] = real_x/2+1
+      CHECK_FFT(hipfftPlanMany(&fwd, rank, n, rdim, 1, (int)(2 * cdist), cdim, 1, (int)cdist, dbl ? HIPFFT_D2Z : HIPFFT_R2C, (int)batch));
+      CHECK_FFT(hipfftPlanMany(&inv, rank, n, cdim, 1, (int)cdist, rdim, 1, (int)(2 * cdist), dbl ? HIPFFT_Z2D : HIPFFT_C2R, (int)batch));
+      CHECK_FFT(hipfftSetStream(inv, stream));
+    }
+    CHECK_FFT(hipfftSetStream(fwd, stream));
+  }
+  template <typename C>
+  void exec(C* data, int direction) {
+    if (!real) {
+      if (dbl) CHECK_FFT(hipfftExecZ2Z(fwd, (hipfftDoubleComplex*)data, (hipfftDoubleComplex*)data, direction));
+      else CHECK_FFT(hipfftExecC2C(fwd, (hipfftComplex*)data, (hipfftComplex*)data, direction));
+    } else if (direction == HIPFFT_FORWARD) {
+      if (dbl) CHECK_FFT(hipfftExecD2Z(fwd, (hipfftDoubleReal*)data, (hipfftDoubleComplex*)data));
+      else CHECK_FFT(hipfftExecR2C(fwd, (hipfftReal*)data, (hipfftComplex*)data));
+    } else {
+      if (dbl) CHECK_FFT(hipfftExecZ2D(inv, (hipfftDoubleComplex*)data, (hipfftDoubleReal*)data));
+      else CHECK_FFT(hipfftExecC2R(inv, (hipfftComplex*)data, (hipfftReal*)data));
+    }
+  }
+  void destroy() {
+    if (inv && inv != fwd) hipfftDestroy(inv);
+    if (fwd) hipfftDestroy(fwd);
+    fwd = inv = 0;
+  }
+};
+
 // 1-D FFTs along global axis `axis` of a pencil, in place
 struct AxisFFT {
   hipfftHandle plan = 0;

@@ -50,6 +50,9 @@ def run(nranks, prog_args, timeout=900):
     r0["gflops"] = round(5.0 * n * math.log2(n) * 1e-9 / (r0["ms_avg"] * 1e-3), 1)
     r0["roundtrip_max_abs_err"] = max(r["roundtrip_max_abs_err"] for r in recs)
     r0["spectrum_rel_err"] = max(r["spectrum_rel_err"] for r in recs)
+    # the ranks' parts of the weighted spectrum checksum add up to a number that does not depend on the decomposition
+    r0["spectrum_checksum"] = [sum(r["spectrum_checksum"][0] for r in recs), sum(r["spectrum_checksum"][1] for r in recs)]
+    r0["spectrum_abs_sum"] = sum(r["spectrum_abs_sum"] for r in recs)
     r0["ok"] = all(r["ok"] for r in recs)
     return r0, logs
 

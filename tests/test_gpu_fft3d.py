@@ -31,6 +31,40 @@ def test_fft3d_four_ranks_peer_transport(pr, pc, extra):
     assert rec["pdims"] == [pr, pc]
 
 
+def _same_spectrum(a, b, rel):
+    da = complex(*a["spectrum_checksum"]) - complex(*b["spectrum_checksum"])
+    return abs(da) <= rel * max(a["spectrum_abs_sum"], b["spectrum_abs_sum"])
+
+
+@pytest.mark.parametrize("mode", [[], ["--r2c"]], ids=["c2c", "r2c"])
+@pytest.mark.parametrize("prec", [[], ["--double"]], ids=["single", "double"])
+@pytest.mark.parametrize("nranks,pr,pc,expect", [(1, 1, 1, "xyz"), (4, 1, 4, "xy"), (4, 4, 1, "yz")])
+def test_fft3d_slab_shortcuts_agree_with_the_plain_passes(nranks, pr, pc, expect, prec, mode):
+    """benchmark.cu:340-373: a process grid with a 1 lets whole planes (or the whole array) be transformed at once --
+    one 3-D FFT on 1x1, 2-D x-y planes on 1xQ, 2-D y-z planes on Px1 (skipping the Y<->Z transposes).  Shortcuts on and off
+    must produce the same spectrum (weighted checksum over global indices, 5e-4 single / 1e-10 double, the round-trip
+    tolerances of benchmark.cu:23-27) and both must pass the plane-wave and round-trip checks; also for the
+    real-to-complex flavour (:238-330), whose decomposed grid is (gx/2+1) x gy x gz."""
+    base = ["--gx", "64", "--gy", "60", "--gz", "68", "--pr", str(pr), "--pc", str(pc), "--backend", "8" if nranks > 1 else "4",
+            "--warmup", "1", "--trials", "2"] + prec + mode
+    on, _ = run_fft3d.run(nranks, base)
+    off, _ = run_fft3d.run(nranks, base + ["--no-slab-opt"])
+    assert on["ok"] and off["ok"], (on, off)
+    assert on["slab"] == expect and off["slab"] == "none", (on["slab"], off["slab"])
+    assert on["mode"] == ("r2c" if mode else "c2c") and on["spectrum_checked"] and off["spectrum_checked"]
+    assert _same_spectrum(on, off, 1e-10 if prec else 5e-4), (on["spectrum_checksum"], off["spectrum_checksum"])
+
+
+def test_fft3d_r2c_round_trip_on_a_pencil_grid():
+    """R2C / C2R on a 2 x 2 pencil grid (no shortcut applies), out of place, odd-ish extents; and the same spectrum as the
+    one-rank single-3-D-FFT run of the same field would need the same random field on every decomposition -- the field is
+    seeded per rank, so only the checks of each run are asserted here."""
+    for extra in ([], ["--double", "-o"], ["--default-layout"]):
+        rec, _ = run_fft3d.run(4, ["--gx", "62", "--gy", "60", "--gz", "68", "--pr", "2", "--pc", "2", "--backend", "8",
+                                   "--warmup", "1", "--trials", "2", "--r2c"] + extra)
+        assert rec["ok"] and rec["mode"] == "r2c" and rec["slab"] == "none", rec
+
+
 @pytest.mark.parametrize("nranks,args", [(1, ["--n", "48"]), (1, ["--n", "32", "--default-layout"]),
                                          (4, ["--n", "48", "--pr", "2", "--pc", "2", "--backend", "1"]),
                                          (4, ["--n", "40", "--pr", "1", "--pc", "4", "--backend", "8", "--default-layout"])])
