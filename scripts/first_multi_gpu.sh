@@ -1,0 +1,95 @@
+#!/bin/bash
+# first_multi_gpu.sh -- ONE command that turns the first lease of a box with several MI355X into the complete evidence
+# set for SURVEY section 8 rows A8 / (e) / (f2): everything that has only ever run with ranks SHARING one GPU.
+#
+#   bash scripts/first_multi_gpu.sh [--gpus N] [--shared] [--quick]
+#
+#   --gpus N   ranks to go up to (default: the GPUs the kernel driver lists; 2, 4, 8 <= N are benchmarked)
+#   --shared   dry run on a one-GPU box: the same steps with the ranks sharing the device (flow check, not a measurement;
+#              the pytest step then only shows its skip reasons)
+#   --quick    smaller problem (256^3) and fewer cycles in the bench steps (dry runs)
+#
+# Steps, in order; every step is bounded by its own timeout and the script goes on if one fails:
+#   1. inventory: GPUs, topology, RCCL / HIP versions
+#   2. link probe of every ordered GPU pair, copy engines and compute-unit stores   (scripts/probe/link_matrix.py)
+#   3. the un-shimmed multi-GPU tests: real RCCL between ranks, cross-device IPC, remote stores, autotuner with every
+#      backend, config 5 halos -- every cell                                       (tests/test_gpu_multi_device.py)
+#   4. bench.py --gpus 2 / 4 / 8 as the driver launches it: every candidate under config.also_measured, the xgmi block
+#      with the MEASURED link rate
+#   5. flags in device memory vs the host-pinned board: tiny-transpose latency and the 1024^3 cycle over NVSHMEM_PL
+#   6. rocprofv3 kernel + memory-copy timeline of one staged NVSHMEM_PL cycle and one config-5-style halo trio
+#   7. summary -> gpurun_out/first_multi_gpu/summary.json next to the model table of DESIGN.md section 7
+#      (copy it to profiles/r04_scale_<N>gpus.json)
+# Everything lands under gpurun_out/first_multi_gpu/.
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/first_multi_gpu
+mkdir -p $OUT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+NGPU=$(python - <<'PY'
+import glob
+n = 0
+for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+    for line in open(f):
+        if line.startswith("simd_count") and int(line.split()[1]) > 0:
+            n += 1
+print(n)
+PY
+)
+MAXR=$NGPU; SHARED=0; QUICK=0
+while [ $# -gt 0 ]; do
+  case "$1" in
+    --gpus) MAXR=$2; shift 2;;
+    --shared) SHARED=1; shift;;
+    --quick) QUICK=1; shift;;
+    *) echo "unknown option $1"; exit 2;;
+  esac
+done
+if [ $SHARED -eq 0 ] && [ $MAXR -gt $NGPU ]; then MAXR=$NGPU; fi
+SIZE=1024; STEPS=5; WARM=3
+if [ $QUICK -eq 1 ]; then SIZE=256; STEPS=2; WARM=1; fi
+echo "first_multi_gpu: $NGPU GPU(s) listed, ranks up to $MAXR, shared=$SHARED, size=$SIZE" | tee $OUT/00_plan.txt
+step() { echo "== $(date +%H:%M:%S) step $1" | tee -a $OUT/00_plan.txt; }
+
+step "1 inventory"
+{ echo "gpus: $NGPU"; (rocm-smi --showtopo 2>&1 || true) | head -60; (rocm-smi --showproductname 2>&1 || true) | head -30;
+  python -c "import torch; print('torch', torch.__version__, 'hip', torch.version.hip, 'devices', torch.cuda.device_count())" 2>&1; } > $OUT/01_inventory.txt
+
+step "2 link matrix"
+timeout 600 python scripts/probe/link_matrix.py 256 > $OUT/02_link_matrix.json 2> $OUT/02_link_matrix.err || echo "link matrix failed (rc $?)" >> $OUT/00_plan.txt
+
+step "3 multi-device tests"
+( time timeout 3000 python -m pytest tests/test_gpu_multi_device.py -q -m gpu -rs --durations=10 ) > $OUT/03_multi_device_tests.log 2>&1
+tail -3 $OUT/03_multi_device_tests.log | tee -a $OUT/00_plan.txt
+
+step "4 bench.py at 2 / 4 / 8 ranks"
+for n in 2 4 8; do
+  [ $n -le $MAXR ] || continue
+  ( time timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2953$n \
+      bench.py --gpus $n --steps $STEPS --warmup $WARM --size $SIZE ) > $OUT/04_bench_n$n.log 2>&1
+  grep -E '^\{' $OUT/04_bench_n$n.log | tail -1 > $OUT/04_bench_n$n.json
+  echo "   n=$n: $(python -c "import json,sys; r=json.load(open('$OUT/04_bench_n$n.json')); print(r['ms_per_step'], 'ms per cycle,', r['config']['transport'], r['config']['pdims'])" 2>&1 | tail -1)" | tee -a $OUT/00_plan.txt
+done
+
+step "5 flags in device memory vs host-pinned board"
+timeout 900 python scripts/probe/flag_latency.py > $OUT/05_flag_latency.json 2> $OUT/05_flag_latency.err || echo "flag latency failed" >> $OUT/00_plan.txt
+for flags in 0 1; do
+  n=$MAXR; [ $n -gt 8 ] && n=8
+  [ $n -ge 2 ] || continue
+  ( CUDECOMP_FLAGS_IN_DEVICE_MEMORY=$flags timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \
+      --master-port 2954$flags bench.py --gpus $n --steps $STEPS --warmup $WARM --size $SIZE --backend peer_pl --pdims 1 $n ) > $OUT/05_bench_peer_pl_flags$flags.log 2>&1
+  grep -E '^\{' $OUT/05_bench_peer_pl_flags$flags.log | tail -1 > $OUT/05_bench_peer_pl_flags$flags.json
+done
+
+step "6 timelines (rocprofv3 kernel + memory-copy trace, no counters)"
+( REPO=$PWD; cd /tmp && export TMPDIR=/tmp
+  for engine in sdma cu; do
+    OVERLAP_ENGINE=$engine timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$OUT/06_prof/$engine -- \
+      python $REPO/scripts/probe/overlap_run.py > $REPO/$OUT/06_prof_$engine.log 2>&1
+  done
+  cd $REPO; python scripts/summarize_overlap.py $OUT/06_prof > $OUT/06_timeline.json 2> $OUT/06_timeline.err
+  find $OUT/06_prof -name "*_trace.csv" -delete; find $OUT/06_prof -name "*agent_info.csv" -delete ) || echo "timeline step failed" >> $OUT/00_plan.txt
+
+step "7 summary"
+python scripts/summarize_first_multi_gpu.py $OUT > $OUT/summary.json 2> $OUT/07_summary.err
+python -c "import json; d=json.load(open('$OUT/summary.json')); print(json.dumps({k: d[k] for k in ('gpus','shared','bench')}, indent=1)[:3000])" 2>&1 | tee -a $OUT/00_plan.txt
+echo "== done; copy $OUT/summary.json to profiles/r04_scale_${MAXR}gpus.json" | tee -a $OUT/00_plan.txt
