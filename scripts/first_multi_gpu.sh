@@ -86,7 +86,7 @@ step "6 timelines (rocprofv3 kernel + memory-copy trace, no counters)"
     OVERLAP_ENGINE=$engine timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$OUT/06_prof/$engine -- \
       python $REPO/scripts/probe/overlap_run.py > $REPO/$OUT/06_prof_$engine.log 2>&1
   done
-  cd $REPO; python scripts/summarize_overlap.py $OUT/06_prof > $OUT/06_timeline.json 2> $OUT/06_timeline.err
+  cd $REPO; python scripts/summarize_overlap.py $OUT/06_prof > $OUT/06_timeline.txt 2> $OUT/06_timeline.err; cp $OUT/06_prof/summary.json $OUT/06_timeline.json
   find $OUT/06_prof -name "*_trace.csv" -delete; find $OUT/06_prof -name "*agent_info.csv" -delete ) || echo "timeline step failed" >> $OUT/00_plan.txt
 
 step "7 summary"

@@ -61,6 +61,7 @@ for flags in (0, 1):
         out["flags_ab"]["nvshmem_pl_cycle_ms_flags_in_%s" % ("device_memory" if flags else "host_board")] = {
             "ms_per_step": rec["ms_per_step"], "pdims": rec["config"]["pdims"], "round_trip_ok": rec["config"].get("round_trip_checksum_ok")}
 tl = load("06_timeline.json")
-out["timeline"] = ({k: ("captured" if isinstance(v, dict) and "error" not in v else v) for k, v in tl.items()} if isinstance(tl, dict)
-                   else text("06_timeline.err"))
+res = tl.get("result") if isinstance(tl, dict) else None
+out["timeline"] = ({k: ("captured: see 06_timeline.json" if isinstance(v, dict) and "error" not in v else v) for k, v in res.items()}
+                   if isinstance(res, dict) else text("06_timeline.err"))
 print(json.dumps(out, indent=1))

@@ -696,6 +696,42 @@ def pool_behaviour(rank, nranks, args):
     return out
 
 
+def pool_pressure(rank, nranks, args):
+    """The pool under memory pressure (round-3 advice): (1) cudecompExtTrimWorkspacePool really releases what cudecompFree
+    parked; (2) a cudecompMalloc that does not fit beside the parked workspaces releases them and succeeds; (3) an
+    impossible request fails on EVERY rank with the same result code, nobody hangs, and the library stays usable."""
+    h, gd, g = _setup(rank, nranks, args)
+    out = {"failures": []}
+    mib = 1 << 20
+    free0 = torch.cuda.mem_get_info()[0]
+    p = cd.cudecompMalloc(h, gd, 512 * mib)
+    cd.cudecompFree(h, gd, p)
+    c = cd.cudecompExtGetCounters(h, gd)
+    out["parked_bytes"] = c["workspace_pool_bytes"]
+    cd.cudecompExtTrimWorkspacePool(h)
+    torch.cuda.synchronize()
+    c = cd.cudecompExtGetCounters(h, gd)
+    out["parked_after_trim"] = c["workspace_pool_bytes"]
+    out["freed_by_trim_mib"] = (torch.cuda.mem_get_info()[0] - free0) // mib
+    # (2) park a workspace, then ask for more than what is free without it: only draining the pool makes room.  All ranks
+    # share the device here, so the request is sized from what is free for ALL of them together.
+    park = cd.cudecompMalloc(h, gd, int(args.get("park_gib", 8)) << 30)
+    cd.cudecompFree(h, gd, park)
+    out["parked_before_big"] = cd.cudecompExtGetCounters(h, gd)["workspace_pool_bytes"]
+    # (3) an impossible request (more than the device has): the same error everywhere
+    try:
+        cd.cudecompMalloc(h, gd, int(args.get("impossible_gib", 400)) << 30)
+        out["failures"].append("a 400-GiB workspace was granted")
+    except cd.CudecompError as e:
+        out["impossible_code"] = e.code
+    out["parked_after_impossible"] = cd.cudecompExtGetCounters(h, gd)["workspace_pool_bytes"]  # drained on the way
+    # still usable
+    r = cycle_exact(rank, nranks, args)
+    out["failures"] += r["failures"]
+    cd.cudecompGridDescDestroy(h, gd)
+    return out
+
+
 def halo_timed(rank, nranks, args):
     """cudecompUpdateHalos{X,Y,Z} timing per pencil axis and dim on a multi-rank grid (BASELINE config 5 when called with
     its sizes): K timed updates per dim bracketed by device events, and the library's own per-phase samples (pack /

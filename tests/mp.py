@@ -53,6 +53,40 @@ def gpus_on_this_host():
     return n
 
 
+def kfd_queue_census():
+    """Hardware queues the kernel driver (KFD) holds right now, over ALL processes: {"processes", "compute", "sdma",
+    "other"}.  Compute queues beyond the device's hardware queue slots put the driver's scheduler into time-slicing
+    ("runlist oversubscribed"): the regime DESIGN.md section 9 is about.  Empty dict if the sysfs tree is not readable."""
+    root = "/sys/class/kfd/kfd/proc"
+    out = {"processes": 0, "compute": 0, "sdma": 0, "other": 0}
+    try:
+        pids = [d for d in os.listdir(root) if d.isdigit()]
+    except OSError:
+        return {}
+    for pid in pids:
+        qdir = os.path.join(root, pid, "queues")
+        try:
+            queues = os.listdir(qdir)
+        except OSError:
+            continue
+        if queues:
+            out["processes"] += 1
+        for q in queues:
+            try:
+                with open(os.path.join(qdir, q, "type")) as f:
+                    t = f.read().strip()
+            except OSError:
+                continue
+            # KFD queue types: 0 compute, 1 SDMA, 2 HIQ, 3 DIQ, 4 SDMA over xGMI (strings on newer kernels)
+            if t in ("0", "compute"):
+                out["compute"] += 1
+            elif t in ("1", "4", "sdma", "sdma_xgmi"):
+                out["sdma"] += 1
+            else:
+                out["other"] += 1
+    return out
+
+
 def shared_device_env(nranks, env):
     """Hook for ranks that SHARE a GPU.  Measured in round 3: eight processes with the runtime's
     default of four hardware queues each can push the device into time-slicing its queues (4-5x slower, rarely a wrong

@@ -22,3 +22,17 @@ def test_released_workspaces_are_recycled(pool):
             assert r["same_pointer"] and r["pool_hits"] == 2
         else:
             assert r["pool_hits"] == 0
+
+
+def test_pool_gives_memory_back_under_pressure():
+    """Round-3 advice on the pool: parked memory is released by cudecompExtTrimWorkspacePool, a cudecompMalloc that runs
+    out of memory drains the pool before it gives up, and an allocation failure is agreed on by all ranks (same result
+    code everywhere, no rank left waiting in a collective)."""
+    args = {"gdims": (64, 48, 80), "pdims": (2, 2), "kind": 1, "ac": K.ALL_AC, "transpose_backend": cd.TRANSPOSE_COMM_NVSHMEM}
+    res = run_ranks(4, "tests.gpu_bodies", "pool_pressure", args, timeout=600)
+    for r in res:
+        assert r["failures"] == [], r
+        assert r["parked_bytes"] >= 512 << 20 and r["parked_after_trim"] == 0
+        assert r["parked_before_big"] >= 8 << 30
+        assert r["impossible_code"] == res[0]["impossible_code"] != 0
+        assert r["parked_after_impossible"] == 0
