@@ -98,7 +98,8 @@ class ExtHaloPlan(C.Structure):
 class ExtCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("graphs_captured", "graph_launches", "local", "rccl", "mpi", "peer_barrier",
                                           "peer_fused", "peer_pipelined", "direct_puts", "workspace_pool_hits",
-                                          "stale_ipc_mappings", "workspace_pool_bytes", "retired_imports")]
+                                          "stale_ipc_mappings", "workspace_pool_bytes", "retired_imports", "compute_queues_on_device",
+                                          "hardware_queue_slots")]
 
 
 class ExtLinkInfo(C.Structure):

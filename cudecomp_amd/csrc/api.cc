@@ -410,6 +410,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     if (const char* v = std::getenv("CUDECOMP_WINDOW_STORES")) h->tuning.window_mode = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
     if (const char* v = std::getenv("CUDECOMP_WINDOW_WIDE")) h->tuning.window_wide = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
     if (const char* v = std::getenv("CUDECOMP_TILE_WALK")) h->tuning.walk_order = (int)std::strtol(v, nullptr, 10);  // tuning aid
+    if (const char* v = std::getenv("CUDECOMP_TILE_SHAPE")) h->tuning.tile_shape = (int)std::strtol(v, nullptr, 10);  // tuning aid
     if (const char* v = std::getenv("CUDECOMP_XCD_WALK")) h->tuning.xcd_walk = (int)std::strtol(v, nullptr, 10);  // diagnostic
     if (const char* v = std::getenv("CUDECOMP_LOCAL_STORE_POLICY")) {  // diagnostic: cached | stream | writethrough
       const std::string e(v);
@@ -597,6 +598,9 @@ cudecompResult_t cudecompGridDescDestroy(cudecompHandle_t handle, cudecompGridDe
     if (one_sided) peerCheckStatus(handle);
     // mappings of user buffers their owners have re-created since are kept open on purpose (transport.cc map()); bound them
     peerTrimRetiredImports(handle, 32);
+    // ranks sharing a device: say so (once) when the device's hardware queues are oversubscribed by now
+    if (handle->peer && handle->nranks > 1 && !handle->link_crosses_devices && !handle->queue_warned)
+      (void)peerQueueCensus(handle, true);
   }
   CD_API_CATCH()
   return CUDECOMP_RESULT_SUCCESS;

@@ -71,6 +71,7 @@ struct cudecompHandle {
   std::string performance_report_write_dir;   // CSV output directory ("" = none)
   bool col_major_env_warned = false;
   bool ipc_warned = false;
+  bool queue_warned = false;          // the "hardware queues oversubscribed" note (ranks sharing a device) was printed
   bool halo_overlap_disable = false;  // CUDECOMP_DISABLE_HALO_OVERLAP=1
   bool halo_overlap_force = false;    // CUDECOMP_FORCE_HALO_OVERLAP=1: also for faces below the size threshold (tests)
   bool self_exchange = false;         // CUDECOMP_TEST_SELF_EXCHANGE=1: one-member communicators exchange with themselves

@@ -753,7 +753,12 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     // lines instead of 2 x five; variant 102)
     const bool wide = c.window && es == 8 && vw == 2 && tuning && tuning->window_wide == 1;
     if (wide) c.variant = 102;
-    const int ti = (es == 16) ? 32 : (wide ? 128 : 64), tj = (c.window && es == 4) ? 128 : ((es == 16) ? 32 : 64);
+    // (4-byte elements, 16-byte lanes, plain kernel: optional 128 x 64 / 64 x 128 tiles -- variants 204 / 304)
+    const int shape = (!c.window && es == 4 && vw == 4 && tuning) ? tuning->tile_shape : 0;
+    if (shape == 1) c.variant = 204;
+    else if (shape == 2) c.variant = 304;
+    const int ti = (es == 16) ? 32 : ((wide || shape == 1) ? 128 : 64);
+    const int tj = ((c.window && es == 4) || shape == 2) ? 128 : ((es == 16) ? 32 : 64);
     c.t0 = (unsigned int)((c.dm.e[0] + ti - 1) / ti);
     c.t1 = (unsigned int)((c.dm.e[1] + (c.window ? 64 / es - 1 : 0) + tj - 1) / tj);
     c.blocks = (unsigned long long)c.t0 * c.t1 * (unsigned long long)c.dm.e[2];
@@ -807,7 +812,9 @@ void launchBatchT(MoveClass cls, int variant, int es, const Batch& b, unsigned i
       break;
     case MOVE_TRANSPOSE:
       if (es == 4) {
-        if (variant == 4) transpose_kernel<4, 4, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
+        if (variant == 204) transpose_kernel<4, 4, 128, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
+        else if (variant == 304) transpose_kernel<4, 4, 64, 128, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
+        else if (variant == 4) transpose_kernel<4, 4, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
         else transpose_kernel<4, 1, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
       } else if (es == 8) {
         if (variant == 2) transpose_kernel<8, 2, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
@@ -837,8 +844,9 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
     snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_window_kernel<%d,%d,%d,%d,%d>", es, variant % 100,
              es == 16 ? 32 : (variant >= 100 ? 128 : 64), es == 16 ? 32 : (es == 4 ? 128 : 64), stream_access);
   else if (cls == MOVE_TRANSPOSE)
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_kernel<%d,%d,%d,%d,%d,%s>", es, variant, es == 16 ? 32 : 64,
-             es == 16 ? 32 : 64, stream_access, swizzle ? "true" : "false");
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_kernel<%d,%d,%d,%d,%d,%s>", es, variant % 100,
+             es == 16 ? 32 : (variant == 204 ? 128 : 64), es == 16 ? 32 : (variant == 304 ? 128 : 64), stream_access,
+             swizzle ? "true" : "false");
   else
     snprintf(g_last_kernel, sizeof(g_last_kernel), "generic_kernel<%d,%s>", es, stream_access == 3 ? "true" : "false");
   if (cls == MOVE_TRANSPOSE && window) {

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include <dirent.h>
 #include <fcntl.h>
 #include <rccl/rccl.h>
 #include <sys/mman.h>
@@ -792,6 +793,74 @@ void peerTrimRetiredImports(cudecompHandle_t h, size_t keep) {
   if (h->peer) h->peer->trimRetiredImports(keep);
 }
 
+namespace {
+bool readSmallFile(const std::string& path, std::string* out) {
+  FILE* f = std::fopen(path.c_str(), "r");
+  if (!f) return false;
+  char buf[256];
+  const size_t n = std::fread(buf, 1, sizeof(buf) - 1, f);
+  std::fclose(f);
+  buf[n] = 0;
+  *out = buf;
+  while (!out->empty() && (out->back() == '\n' || out->back() == ' ')) out->pop_back();
+  return true;
+}
+std::vector<std::string> listDir(const std::string& path) {
+  std::vector<std::string> out;
+  if (DIR* d = ::opendir(path.c_str())) {
+    while (dirent* e = ::readdir(d))
+      if (e->d_name[0] != '.') out.push_back(e->d_name);
+    ::closedir(d);
+  }
+  return out;
+}
+}  // namespace
+
+int peerQueueCensus(cudecompHandle_t h, bool warn, int* slots_out) {
+  const std::string root = "/sys/class/kfd/kfd/proc";
+  // the KFD id(s) of the GPU(s) this process has queues on
+  std::vector<std::string> mine;
+  const std::string me = root + "/" + std::to_string((long long)::getpid()) + "/queues";
+  for (const std::string& q : listDir(me)) {
+    std::string id;
+    if (readSmallFile(me + "/" + q + "/gpuid", &id) && std::find(mine.begin(), mine.end(), id) == mine.end()) mine.push_back(id);
+  }
+  if (mine.empty()) return -1;
+  int compute = 0;
+  for (const std::string& pid : listDir(root)) {
+    const std::string qd = root + "/" + pid + "/queues";
+    for (const std::string& q : listDir(qd)) {
+      std::string id, type;
+      if (!readSmallFile(qd + "/" + q + "/gpuid", &id) || std::find(mine.begin(), mine.end(), id) == mine.end()) continue;
+      if (readSmallFile(qd + "/" + q + "/type", &type) && (type == "0" || type == "compute")) ++compute;
+    }
+  }
+  // hardware queue slots for user compute queues: the topology node of that GPU says (num_cp_queues); 24 on the parts
+  // this was written on when the driver does not
+  int slots = 24;
+  const std::string nodes = "/sys/class/kfd/kfd/topology/nodes";
+  for (const std::string& n : listDir(nodes)) {
+    std::string id;
+    if (!readSmallFile(nodes + "/" + n + "/gpu_id", &id) || id != mine[0]) continue;
+    if (FILE* f = std::fopen((nodes + "/" + n + "/properties").c_str(), "r")) {
+      char key[64];
+      long long val = 0;
+      while (std::fscanf(f, "%63s %lld", key, &val) == 2)
+        if (!std::strcmp(key, "num_cp_queues") && val > 0) slots = (int)val;
+      std::fclose(f);
+    }
+  }
+  if (slots_out) *slots_out = slots;
+  if (warn && compute > slots && !h->queue_warned) {
+    h->queue_warned = true;
+    fprintf(stderr, "CUDECOMP:WARN: rank %d: the processes sharing this GPU hold %d compute queues, more than its %d hardware queue "
+                    "slots: the kernel driver time-slices ALL of them (expect every GPU operation to take several times longer; rare "
+                    "wrong results of kernels of any kind were observed in this regime).  Use fewer processes or streams per GPU.\n",
+            h->rank, compute, slots);
+  }
+  return compute;
+}
+
 void peerCheckStatus(cudecompHandle_t h) {
   if (h->peer) h->peer->checkStatus();
 }
@@ -955,6 +1024,7 @@ void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
     h->peer->agreePoolLimit();
     if (!h->boot->allreduceOr(!have_dev)) h->peer->setupDeviceFlags();  // (geometry-only jobs have no device)
     peerMeasureLink(h);
+    if (h->nranks > 1 && !h->link_crosses_devices && have_dev) (void)peerQueueCensus(h, true);  // ranks share a device
   }
 }
 

@@ -38,6 +38,11 @@ uint64_t peerSlotHigh(cudecompHandle_t h, int slot);
 // cudecompMalloc calls served from the pool of released workspaces / new IPC mappings found stale (0, 0 without a peer transport)
 void peerPoolCounters(cudecompHandle_t h, int64_t* pool_hits, int64_t* stale_mappings, int64_t* pool_bytes = nullptr,
                       int64_t* retired_imports = nullptr);
+// Ranks that SHARE a device (test boxes): count the user compute queues the kernel driver holds on this process's GPU
+// (sysfs, /sys/class/kfd/kfd/proc/*/queues) and say so once when they exceed the device's hardware queue slots -- the
+// driver then time-slices every process of the device.  Best effort, never fails; returns the
+// count (-1 if the driver's tables are not readable) and the slots through *slots.
+int peerQueueCensus(cudecompHandle_t h, bool warn, int* slots = nullptr);
 // throws if a device-side wait of an earlier one-sided exchange gave up (dead peer)
 void peerCheckStatus(cudecompHandle_t h);
 // one-direction copy rate to the next rank through both copy engines (collective; fills h->link_gbps_*)

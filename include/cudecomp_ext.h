@@ -149,6 +149,10 @@ typedef struct {
   /* per HANDLE: bytes cudecompFree has parked in the workspace pool right now; IPC mappings of re-created user buffers
    * that are kept open (the newest 32 survive a cudecompGridDescDestroy) */
   int64_t workspace_pool_bytes, retired_imports;
+  /* user compute queues the kernel driver holds on this process's GPU right now, over ALL processes (-1: not readable),
+   * and the hardware queue slots that GPU has for them: more queues than slots = the driver time-slices every process of
+   * the device (ranks sharing a GPU) */
+  int64_t compute_queues_on_device, hardware_queue_slots;
 } cudecompExtCounters_t;
 cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
                                         cudecompExtCounters_t* counters);
@@ -185,7 +189,8 @@ cudecompResult_t cudecompExtEstimateCycleMs(cudecompHandle_t handle, const cudec
  * force_generic is a bit mask: 1 selects the element-wise fallback kernel, 2 forces the streaming
  * (non-temporal) variants that are normally used only for moves of 32 MiB and more, 4 selects the window variant of
  * the LDS transpose for every destination off the 64-byte grid (normally only for moves of 1 MiB and more), 8 disables
- * it.  *kernel_class (optional) receives the
+ * it; 16 / 32: 128 x 64 / 64 x 128 tiles for 4-byte transposes (tuning variants); 64: write-through stores, 128:
+ * round-robin tile walk (diagnostic variants).  *kernel_class (optional) receives the
  * kernel flavour used: 0 rows, 1 LDS transpose, 2 generic. */
 cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const int64_t extent[3],
                                    const int64_t ss[3], const int64_t ds[3], int32_t force_generic,

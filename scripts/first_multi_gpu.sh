@@ -29,9 +29,12 @@ NGPU=$(python - <<'PY'
 import glob
 n = 0
 for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-    for line in open(f):
-        if line.startswith("simd_count") and int(line.split()[1]) > 0:
-            n += 1
+    try:
+        for line in open(f):
+            if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                n += 1
+    except (OSError, ValueError):
+        pass
 print(n)
 PY
 )

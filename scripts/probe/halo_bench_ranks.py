@@ -14,13 +14,17 @@ import cudecomp_amd as cd  # noqa: E402
 from tests.mp import run_ranks  # noqa: E402
 
 args = {"gdims": (2048, 2048, 1024), "pdims": (2, 4), "kind": 1, "halo": (2, 2, 2), "periods": (1, 1, 1), "axes": [0, 1, 2]}
-out = {"workload": "2048x2048x1024 fp64, 2x4 grid, halo 2, periodic; 8 ranks", "variants": {}}
+nranks = 8
+if os.environ.get("HALO_BENCH_GRID") == "2x2":  # the same per-rank pencils on four ranks (at most four ranks per GPU)
+    args["gdims"], args["pdims"], nranks = (2048, 2048, 512), (2, 2), 4
+out = {"workload": "%dx%dx%d fp64, %dx%d grid, halo 2, periodic; %d ranks" % (tuple(args["gdims"]) + tuple(args["pdims"]) + (nranks,)),
+       "flags": "device memory" if os.environ.get("CUDECOMP_FLAGS_IN_DEVICE_MEMORY") == "1" else "host-pinned board", "variants": {}}
 for name, backend, env in (("nvshmem_overlapped", cd.HALO_COMM_NVSHMEM, {}),
                            ("nvshmem_plain", cd.HALO_COMM_NVSHMEM, {"CUDECOMP_DISABLE_HALO_OVERLAP": "1"}),
                            ("mpi_plain", cd.HALO_COMM_MPI, {"CUDECOMP_DISABLE_HALO_OVERLAP": "1"})):
     env = dict(env, CUDECOMP_ENABLE_PERFORMANCE_REPORT="1", CUDECOMP_PERFORMANCE_REPORT_WARMUP_SAMPLES="3",
                CUDECOMP_PERFORMANCE_REPORT_SAMPLES="10")
-    res = run_ranks(8, "tests.gpu_bodies", "halo_timed", dict(args, halo_backend=backend), timeout=900, extra_env=env)
+    res = run_ranks(nranks, "tests.gpu_bodies", "halo_timed", dict(args, halo_backend=backend), timeout=900, extra_env=env)
     # max over ranks per entry (the slowest rank is what an application sees)
     merged = {}
     for ax in "XYZ":

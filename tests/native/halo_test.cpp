@@ -90,6 +90,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
   }
   T_CHECK_HIP(hipFree(data));
   T_CHECK_CD(cudecompFree(handle, gdesc, work));
+  notePaths(handle, gdesc);
   T_CHECK_CD(cudecompGridDescDestroy(handle, gdesc));
   return failures ? 1 : 0;
 }

@@ -145,9 +145,16 @@ inline int64_t& mpiPathTransposes() {
   static int64_t n = 0;
   return n;
 }
+inline int64_t (&queueCensus())[2] {  // max compute queues seen on the device, its hardware queue slots
+  static int64_t v[2] = {-1, 0};
+  return v;
+}
 inline void notePaths(cudecompHandle_t handle, cudecompGridDesc_t gdesc) {
   cudecompExtCounters_t c;
-  if (cudecompExtGetCounters(handle, gdesc, &c) == CUDECOMP_RESULT_SUCCESS) mpiPathTransposes() += c.mpi;
+  if (cudecompExtGetCounters(handle, gdesc, &c) != CUDECOMP_RESULT_SUCCESS) return;
+  mpiPathTransposes() += c.mpi;
+  if (c.compute_queues_on_device > queueCensus()[0]) queueCensus()[0] = c.compute_queues_on_device;
+  queueCensus()[1] = c.hardware_queue_slots;
 }
 
 // Verdict of a case over all ranks without MPI: every rank drops a one-byte file into a job directory under /dev/shm,
@@ -454,6 +461,9 @@ int nativeMain(int argc, char** argv, RunCase run_case) {
     MPI_Finalize();
   }
 #endif
+  if (rank == 0 && queueCensus()[0] >= 0)  // (ranks sharing a GPU: more compute queues than slots = the driver time-slices them)
+    printf("Device queues: at most %lld compute queues of all processes on this GPU, %lld hardware queue slots\n",
+           (long long)queueCensus()[0], (long long)queueCensus()[1]);
   if (rank == 0) {
     if (from_file) printf("Completed all tests, running time %f s,\n", elapsed());
     if (failed.empty()) {
