@@ -95,11 +95,25 @@ class ExtHaloPlan(C.Structure):
                 ("send_off", C.c_int64 * 2), ("recv_off", C.c_int64 * 2), ("pre", ExtMove * 2), ("post", ExtMove * 2)]
 
 
+class ExtRelayMove(C.Structure):
+    _fields_ = [("dst_rank", C.c_int32), ("to_relay", C.c_int32), ("src_off", C.c_int64), ("dst_off", C.c_int64),
+                ("count", C.c_int64)]
+
+
+EXT_MAX_RELAY_MOVES = 2 * 64 * 4
+
+
+class ExtRelayPlan(C.Structure):
+    _fields_ = [("applies", C.c_int32), ("nranks", C.c_int32), ("slots_per_source", C.c_int32), ("n_scatter", C.c_int32),
+                ("n_forward", C.c_int32), ("reserved", C.c_int32), ("slot_elements", C.c_int64), ("relay_elements", C.c_int64),
+                ("scatter", ExtRelayMove * EXT_MAX_RELAY_MOVES), ("forward", ExtRelayMove * EXT_MAX_RELAY_MOVES)]
+
+
 class ExtCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("graphs_captured", "graph_launches", "local", "rccl", "mpi", "peer_barrier",
                                           "peer_fused", "peer_pipelined", "direct_puts", "workspace_pool_hits",
                                           "stale_ipc_mappings", "workspace_pool_bytes", "retired_imports", "compute_queues_on_device",
-                                          "hardware_queue_slots")]
+                                          "hardware_queue_slots", "relayed")]
 
 
 class ExtLinkInfo(C.Structure):
@@ -127,7 +141,7 @@ EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecom
                "cudecompExtGetTransposeTimings", "cudecompExtGetHaloTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
                "cudecompExtPlanTranspose", "cudecompExtPlanHalo", "cudecompExtPencilInfo", "cudecompExtShiftedRank",
                "cudecompExtWorkspaceSizes", "cudecompExtGetLinkInfo", "cudecompExtLastKernelName",
-               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs", "cudecompExtTrimWorkspacePool"]
+               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs", "cudecompExtTrimWorkspacePool", "cudecompExtPlanRelay"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -201,6 +215,8 @@ def lib():
         L.cudecompExtShiftedRank.argtypes = [C.POINTER(ExtGridSpec), i32, i32, i32, i32, C.c_bool, pi32]
         L.cudecompExtWorkspaceSizes.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, C.POINTER(C.c_int64),
                                                 C.POINTER(C.c_int64)]
+        L.cudecompExtPlanRelay.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, pi32, pi32, C.c_bool,
+                                           C.POINTER(ExtRelayPlan)]
         L.cudecompExtPlanHalo.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, C.POINTER(C.c_bool), i32, pi32, i32,
                                           C.POINTER(ExtHaloPlan)]
         L.cudecompExtGetLinkInfo.argtypes = [vp, C.POINTER(ExtLinkInfo)]
@@ -384,6 +400,14 @@ def cudecompExtPlanTranspose(grid, rank, op, in_halo=None, out_halo=None, in_pad
     _check(lib().cudecompExtPlanTranspose(C.byref(grid), rank, OPS.index(op), _i3(in_halo), _i3(out_halo), _i3(in_pad),
                                           _i3(out_pad), bool(inplace), int(pipelined), int(symmetric_recv), npergroup,
                                           C.byref(p)), "cudecompExtPlanTranspose")
+    return p
+
+
+def cudecompExtPlanRelay(grid, rank, op, in_halo=None, out_halo=None, in_pad=None, out_pad=None, inplace=False):
+    """Two-hop relay moves of `rank` for transpose `op` (stateless; see cudecomp_ext.h)."""
+    p = ExtRelayPlan()
+    _check(lib().cudecompExtPlanRelay(C.byref(grid), rank, OPS.index(op), _i3(in_halo), _i3(out_halo), _i3(in_pad),
+                                      _i3(out_pad), bool(inplace), C.byref(p)), "cudecompExtPlanRelay")
     return p
 
 

@@ -218,6 +218,7 @@ void ensureDevice(cudecompHandle_t h) {
 void resetCommInfo(cudecompGridDesc_t gd) {
   gd->row.release();
   gd->col.release();
+  gd->world.release();
 }
 
 // Row / column communicators of the process grid.  Members of my row share pidx[0]; they are ordered by
@@ -270,6 +271,27 @@ void buildCommInfo(cudecompHandle_t h, cudecompGridDesc_t gd) {
     if (h->nranks > 1) high = (uint64_t)h->boot->allreduceMaxI64((int64_t)high);
     ci.barrier_epoch = ci.mail_seq = ci.epoch_base = high;
   }
+  // the two-hop relay orders its two steps with flags of a communicator of ALL ranks
+  if (h->two_hop_relay && h->nranks >= 4) {
+    cudecompCommInfo& ci = gd->world;
+    ci.owner = h;
+    ci.barrier_slot = h->acquireSlot();
+    ci.nranks = h->nranks;
+    ci.rank = h->rank;
+    ci.boot = h->boot->split(0, h->rank);
+    ci.global_ranks.resize(ci.nranks);
+    std::map<std::string, int> per_host;
+    for (int i = 0; i < ci.nranks; ++i) {
+      ci.global_ranks[i] = i;
+      per_host[h->hostnames[i]]++;
+    }
+    ci.ngroups = (int)per_host.size();  // (the relay needs one node: ngroups == 1)
+    ci.npergroup = ci.nranks / std::max(ci.ngroups, 1);
+    uint64_t high = 0;
+    if (ci.barrier_slot >= 0) high = std::max<uint64_t>(h->slot_high[ci.barrier_slot], peerSlotHigh(h, ci.barrier_slot));
+    high = (uint64_t)h->boot->allreduceMaxI64((int64_t)high);
+    ci.barrier_epoch = ci.mail_seq = ci.epoch_base = high;
+  }
 }
 
 }  // namespace cudecomp
@@ -313,6 +335,13 @@ void cudecompCommInfo::release() {
 cudecompCommInfo::~cudecompCommInfo() { release(); }
 
 cudecompHandle::~cudecompHandle() {
+  if (relay_buf && peer) {
+    try {
+      cudecomp::workspaceFreeRaw(this, relay_buf);  // (collective, like the cudecompFinalize it runs in)
+    } catch (...) {
+    }
+    relay_buf = nullptr;
+  }
   for (hipStream_t s : streams) (void)hipStreamDestroy(s);
   rccl.reset();
   peer.reset();
@@ -381,6 +410,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->self_exchange = envIsOne("CUDECOMP_TEST_SELF_EXCHANGE");
     if (const char* v = std::getenv("CUDECOMP_RCCL_NATIVE_ALLTOALL")) h->rccl_native_alltoall = std::strtol(v, nullptr, 10) != 0;
     h->direct_put = !envIsOne("CUDECOMP_DISABLE_DIRECT_PUT");
+    h->two_hop_relay = envIsOne("CUDECOMP_TWO_HOP_RELAY");
     h->debug_verify_exchange = envIsOne("CUDECOMP_DEBUG_VERIFY_EXCHANGE");
     if (const char* v = std::getenv("CUDECOMP_PIPELINE_MIN_STAGE_MIB")) h->pipeline_min_stage_bytes = std::strtoll(v, nullptr, 10) << 20;
     if (const char* v = std::getenv("CUDECOMP_PIPELINE_STAGES")) {
@@ -576,6 +606,7 @@ cudecompResult_t cudecompGridDescCreateVersioned(cudecompHandle_t handle, cudeco
 
     buildCommInfo(handle, gd);
     gd->transpose_plans.clear();
+    gd->relay_plans.clear();
     gd->halo_plans.clear();
     perfReset(gd);  // autotuning trials are not part of the user's performance report
 

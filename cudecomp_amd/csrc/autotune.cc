@@ -395,6 +395,7 @@ void autotuneTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecomp
 
     buildCommInfo(h, gd);  // test row / column communicators
     gd->transpose_plans.clear();
+    gd->relay_plans.clear();
 
     // pencils of the four hops with the halos / padding requested for each
     Pencil px0 = makePencil(gd->shape, gd->pidx, 0, opt->transpose_input_halo_extents[0], opt->transpose_input_padding[0]);
@@ -431,6 +432,7 @@ void autotuneTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecomp
     for (auto backend : backends) {
       gd->config.transpose_comm_backend = backend;
       gd->transpose_plans.clear();
+      gd->relay_plans.clear();
       // A candidate that cannot run here (e.g. a transport that fails to initialise on this system) is
       // dropped on every rank instead of aborting the sweep.
       bool failed = false;
@@ -523,6 +525,7 @@ void autotuneTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const cudecomp
   gd->config.pdims[1] = pick.pdims[1];
   gd->config.transpose_comm_backend = (cudecompTransposeCommBackend_t)pick.backend;
   gd->transpose_plans.clear();
+  gd->relay_plans.clear();
   if (!valid) CD_NOT_SUPPORTED("No valid decomposition found during autotuning with provided arguments.");
 
   if (h->rank == 0)

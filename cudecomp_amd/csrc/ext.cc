@@ -232,6 +232,43 @@ cudecompResult_t cudecompExtPlanTranspose(const cudecompExtGridSpec_t* grid, int
   return CUDECOMP_RESULT_SUCCESS;
 }
 
+cudecompResult_t cudecompExtPlanRelay(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t op, const int32_t in_halo[],
+                                      const int32_t out_halo[], const int32_t in_pad[], const int32_t out_pad[], bool inplace,
+                                      cudecompExtRelayPlan_t* out) {
+  try {
+    const GridShape g = shapeFromSpec(grid);
+    if (!out) CD_INVALID_USAGE("plan argument cannot be null");
+    if (op < 0 || op > 3) CD_INVALID_USAGE("op out of range");
+    const int n = g.pdims[0] * g.pdims[1];
+    if (rank < 0 || rank >= n) CD_INVALID_USAGE("rank out of range");
+    TransportTraits traits;
+    traits.symmetric_recv = true;
+    const CommAxis ca = (op == OP_X_TO_Y || op == OP_Y_TO_X) ? COMM_COL : COMM_ROW;
+    const RelayPlan rp = buildRelayPlan(g, n, rank, (TransposeOp)op, in_halo, out_halo, in_pad, out_pad, inplace, traits,
+                                        g.pdims[ca == COMM_COL ? 0 : 1]);
+    std::memset(out, 0, sizeof(*out));
+    out->applies = rp.applies ? 1 : 0;
+    out->nranks = rp.nranks;
+    out->slots_per_source = rp.slots_per_source;
+    out->slot_elements = rp.slot_elements;
+    out->relay_elements = rp.relayElements();
+    if ((int)rp.scatter.size() > CUDECOMP_EXT_MAX_RELAY_MOVES || (int)rp.forward.size() > CUDECOMP_EXT_MAX_RELAY_MOVES)
+      CD_NOT_SUPPORTED("relay plan too large for the export structure");
+    auto put = [](const std::vector<RelayMove>& v, cudecompExtRelayMove_t* o) {
+      for (size_t k = 0; k < v.size(); ++k) o[k] = {v[k].dst_rank, v[k].to_relay ? 1 : 0, v[k].src_off, v[k].dst_off, v[k].count};
+    };
+    out->n_scatter = (int32_t)rp.scatter.size();
+    out->n_forward = (int32_t)rp.forward.size();
+    put(rp.scatter, out->scatter);
+    put(rp.forward, out->forward);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
 cudecompResult_t cudecompExtPlanHalo(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis, const int32_t halo[],
                                      const bool periods[], int32_t dim, const int32_t pad[], int32_t force_packed,
                                      cudecompExtHaloPlan_t* out) {
@@ -331,6 +368,7 @@ cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDes
     int slots = 0;
     out->compute_queues_on_device = peerQueueCensus(handle, false, &slots);
     out->hardware_queue_slots = slots;
+    out->relayed = gd->relayed;
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {

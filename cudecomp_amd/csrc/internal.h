@@ -71,6 +71,9 @@ struct cudecompHandle {
   std::string performance_report_write_dir;   // CSV output directory ("" = none)
   bool col_major_env_warned = false;
   bool ipc_warned = false;
+  bool two_hop_relay = false;         // CUDECOMP_TWO_HOP_RELAY=1: low-fan-out exchanges of the NVSHMEM enum travel through all ranks of the node
+  void* relay_buf = nullptr;          // my relay region (a library region mapped into every rank), grown on demand
+  size_t relay_bytes = 0;
   bool queue_warned = false;          // the "hardware queues oversubscribed" note (ranks sharing a device) was printed
   bool halo_overlap_disable = false;  // CUDECOMP_DISABLE_HALO_OVERLAP=1
   bool halo_overlap_force = false;    // CUDECOMP_FORCE_HALO_OVERLAP=1: also for faces below the size threshold (tests)
@@ -112,6 +115,9 @@ struct cudecompGridDesc {
   cudecomp::GridShape shape;
   std::array<int32_t, 2> pidx{};
   cudecompCommInfo row, col;
+  cudecompCommInfo world;  // all ranks of the handle (only built for the two-hop relay, CUDECOMP_TWO_HOP_RELAY=1)
+  std::map<std::tuple<int, std::array<int32_t, 12>, bool, bool, bool>, cudecomp::RelayPlan> relay_plans;
+  int64_t relayed = 0;     // transposes whose exchange went through the two-hop relay
 
   std::vector<hipEvent_t> events;  // one per communicator member, for per-peer pipelining
 

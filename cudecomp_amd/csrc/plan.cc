@@ -345,4 +345,51 @@ int normalizeMove(Move3D& m) {
   return n;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// two-hop relay (plan.h)
+// ---------------------------------------------------------------------------------------------------------------
+RelayPlan buildRelayPlan(const GridShape& g, int nranks, int rank, TransposeOp op, const int32_t* in_halo,
+                         const int32_t* out_halo, const int32_t* in_pad, const int32_t* out_pad, bool inplace,
+                         const TransportTraits& traits, int npergroup) {
+  RelayPlan rp;
+  rp.nranks = nranks;
+  if (nranks != g.pdims[0] * g.pdims[1]) return rp;
+  // the plans of all ranks (cheap: index math only)
+  std::vector<TransposePlan> plans;
+  plans.reserve(nranks);
+  for (int s = 0; s < nranks; ++s) plans.push_back(buildTransposePlan(g, s, op, in_halo, out_halo, in_pad, out_pad, inplace, traits, npergroup));
+  const TransposePlan& mine = plans[rank];
+  if (!mine.exchange || !relayWorthwhile(mine.nranks, nranks)) return rp;
+  const int P = mine.nranks;
+  rp.slots_per_source = P - 1;
+  for (const TransposePlan& p : plans)
+    for (int i = 0; i < P; ++i)
+      if (i != p.comm_rank) rp.slot_elements = std::max(rp.slot_elements, (p.send_cnt[i] + nranks - 1) / nranks);
+  rp.slot_elements = alignElements(rp.slot_elements);  // slots start on 256-byte boundaries
+  for (int s = 0; s < nranks; ++s) {
+    const TransposePlan& p = plans[s];
+    const auto pidx = gridIndexOfRank(g, s);
+    int j = 0;  // index among the chunks s sends
+    for (int i = 0; i < P; ++i) {
+      if (i == p.comm_rank) continue;
+      const int d = globalRankOf(g, pidx, p.comm_axis, i);
+      const i64 cnt = p.send_cnt[i];
+      for (int q = 0; q < nranks; ++q) {
+        const i64 lo = cnt * q / nranks, hi = cnt * (q + 1) / nranks;
+        if (hi == lo) continue;
+        const i64 slot = ((i64)s * (P - 1) + j) * rp.slot_elements;
+        if (q == s || q == d) {  // straight to the destination
+          if (s == rank) rp.scatter.push_back({d, false, p.send_off[i] + lo, p.remote_recv_off[i] + lo, hi - lo});
+        } else {
+          if (s == rank) rp.scatter.push_back({q, true, p.send_off[i] + lo, slot, hi - lo});
+          if (q == rank) rp.forward.push_back({d, false, slot, p.remote_recv_off[i] + lo, hi - lo});
+        }
+      }
+      ++j;
+    }
+  }
+  rp.applies = true;
+  return rp;
+}
+
 }  // namespace cudecomp

@@ -83,6 +83,40 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
                                  const int32_t* out_halo, const int32_t* in_pad, const int32_t* out_pad, bool inplace,
                                  const TransportTraits& traits, int npergroup);
 
+// ---- two-hop relay of a low-fan-out exchange over the whole node (transport.cc: peerRelayAlltoall) ----------------------
+// On a full xGMI mesh an exchange among P members drives P - 1 of a GPU's links.  On a pencil grid P is small -- the
+// X<->Y exchange of a 2 x 4 grid has P = 2: half a pencil through ONE link while six links idle.  Here every outgoing chunk
+// is cut into `nranks` equal slices (nranks = all ranks of the node); slice q travels source -> rank q -> destination, the
+// slices q = source and q = destination go straight to the destination.  Every link then carries two slices per direction
+// instead of one link carrying the whole chunk: wire time / (nranks / 2), paid with one extra HBM round trip of the relayed
+// bytes at the relays.  (The grouping idea of the reference's schedule, include/internal/common.h:533-577, taken one step
+// further; nothing like it exists there.)
+//   step 1 "scatter": my slices -> relay regions of the ranks q (relay slot of (source, chunk index)) / receive area of the
+//                     destination for the two direct slices;
+//   step 2 "forward": what arrived in MY relay region -> the receive areas of its destinations.
+// Every rank derives the moves of every other rank from the decomposition alone (the planner is stateless), so the
+// forwarder knows where a slice must go without any metadata travelling with it.
+struct RelayMove {
+  int dst_rank = 0;      // GLOBAL rank whose memory is written
+  bool to_relay = false; // destination is that rank's relay region (else its receive area)
+  i64 src_off = 0;       // scatter: elements from the start of my send area; forward: elements into MY relay region
+  i64 dst_off = 0;       // elements into the destination's relay region / receive area
+  i64 count = 0;
+};
+struct RelayPlan {
+  bool applies = false;
+  int nranks = 0;            // ranks of the node (= of the handle)
+  int slots_per_source = 0;  // chunks a rank sends = P - 1
+  i64 slot_elements = 0;     // size of one relay slot = the largest slice of the decomposition
+  std::vector<RelayMove> scatter, forward;
+  i64 relayElements() const { return (i64)nranks * slots_per_source * slot_elements; }
+};
+// worth it when the exchange uses at most a third of the links a rank has
+inline bool relayWorthwhile(int P, int nranks) { return P >= 2 && nranks >= 4 && 3 * (P - 1) <= nranks - 1; }
+RelayPlan buildRelayPlan(const GridShape& g, int nranks, int rank, TransposeOp op, const int32_t* in_halo,
+                         const int32_t* out_halo, const int32_t* in_pad, const int32_t* out_pad, bool inplace,
+                         const TransportTraits& traits, int npergroup);
+
 struct HaloPlan {
   int axis = 0, dim = 0;
   enum Kind { NONE, SELF_PERIODIC, PACKED, DIRECT } kind = NONE;

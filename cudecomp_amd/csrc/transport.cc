@@ -1384,6 +1384,82 @@ void peerPutExchange(cudecompHandle_t h, cudecompCommInfo& ci, const TransposePl
   launchWait(call.epoch, incoming, pc.dStatus(), h->peer_timeout_s, stream);
 }
 
+// ---- two-hop relay (plan.h RelayPlan) -----------------------------------------------------------
+bool peerRelayApplies(cudecompHandle_t h, cudecompGridDesc_t gd, const TransposePlan& plan, cudecompTransposeCommBackend_t backend,
+                      bool inplace) {
+  (void)inplace;
+  if (!h->two_hop_relay || backend != CUDECOMP_TRANSPOSE_COMM_NVSHMEM || !plan.exchange || h->self_exchange) return false;
+  if (!relayWorthwhile(plan.nranks, h->nranks)) return false;
+  // flags of a communicator of all ranks, all of them on this node and on the shared board
+  return h->peer && gd->world.nranks == h->nranks && h->nranks <= kMaxFlags && h->peer->usable(gd->world);
+}
+
+void peerRelayEnsureRegion(cudecompHandle_t h, const RelayPlan& rp, int es) {
+  // the same number on every rank (it is derived from the whole decomposition), so this is collective by construction
+  const size_t need = (size_t)rp.relayElements() * es;
+  if (h->relay_buf && h->relay_bytes >= need) return;
+  if (h->relay_buf) workspaceFreeRaw(h, h->relay_buf);
+  h->relay_buf = nullptr;
+  h->relay_bytes = 0;
+  void* p = workspaceAllocRaw(h, need, true);
+  PeerContext::Region* r = h->peer->find(p);
+  bool ok = r != nullptr;
+  for (int g = 0; ok && g < h->nranks; ++g) ok = r->peer_base[g] != nullptr;
+  if (h->boot->allreduceOr(!ok)) {
+    workspaceFreeRaw(h, p);
+    CD_PEER_ERROR("the relay region of the two-hop exchange could not be mapped into every rank of the node");
+  }
+  h->relay_buf = p;
+  h->relay_bytes = need;
+}
+
+void peerRelayAlltoall(cudecompHandle_t h, cudecompCommInfo& world, const TransposePlan& p, const RelayPlan& rp,
+                       const ExchangeBuffers& b, int es, const PeerCall& call, hipStream_t stream) {
+  PeerContext& pc = peerOf(h, world);
+  const int n = world.nranks, me = h->rank, slot = world.barrier_slot;
+  PeerContext::Region* rr = pc.find(h->relay_buf);
+  if (!rr) CD_INTERNAL_ERROR("two-hop relay without its relay region");
+  FlagList ready, landed, incoming;
+  for (int q = 0; q < n; ++q) {
+    if (q == me) continue;
+    ready.add(pc.dReady(slot, q));
+    landed.add(pc.dLanded(slot, q, me));
+    incoming.add(pc.dLanded(slot, me, q));
+  }
+  // every rank has begun this call: its relay slots (forwarded in its previous call, earlier on its stream) and its
+  // receive area are free
+  launchWait(call.epoch, ready, pc.dStatus(), h->peer_timeout_s, stream, kFlagBegun);
+  auto run = [&](const std::vector<RelayMove>& list, char* src_base) {
+    std::vector<Move3D> moves;
+    std::vector<void*> dst_base;
+    for (const RelayMove& m : list) {
+      Move3D r;
+      r.src_buf = BUF_IN;
+      r.src_off = m.src_off;
+      r.dst_off = m.dst_off;
+      r.extent[0] = m.count;
+      r.ss[0] = r.ds[0] = 1;
+      r.peer = m.dst_rank;
+      moves.push_back(r);
+      dst_base.push_back(m.to_relay ? rr->peer_base[m.dst_rank] : call.remote_recv[m.dst_rank]);
+    }
+    void* bufs[3] = {src_base, nullptr, nullptr};
+    if (!moves.empty()) launchMoves(moves.data(), (int)moves.size(), bufs, es, stream, &h->tuning, nullptr, dst_base.data());
+  };
+  // step 1: my slices to the relays (and the two direct slices of every chunk to its destination)
+  run(rp.scatter, b.send);
+  launchSignal(call.epoch, landed, stream, 1);
+  // my own chunk never leaves the device (reference: comm_routines.h:405-410)
+  if (p.send_cnt[p.comm_rank])
+    peerCopy(h, b.recv + p.recv_off[p.comm_rank] * es, b.send + p.send_off[p.comm_rank] * es, (size_t)p.send_cnt[p.comm_rank] * es, stream, 0);
+  // step 2: what the others parked in my relay region goes on to its destinations
+  launchWait(call.epoch, incoming, pc.dStatus(), h->peer_timeout_s, stream, 1);
+  run(rp.forward, static_cast<char*>(h->relay_buf));
+  launchSignal(call.epoch, landed, stream, kFlagDone);
+  // everybody's direct slices (done before their step-1 signal) and forwards have reached my receive area
+  launchWait(call.epoch, incoming, pc.dStatus(), h->peer_timeout_s, stream, kFlagDone);
+}
+
 bool peerPipelineAvailable(cudecompHandle_t h, const cudecompCommInfo& ci) { return h->peer && h->peer->usable(ci); }
 
 // CUDECOMP_DEBUG_VERIFY_EXCHANGE=1 (host-synchronous debugging aid): after a one-sided exchange,

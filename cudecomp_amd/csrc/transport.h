@@ -84,6 +84,15 @@ struct PeerCall {
 PeerCall peerBegin(cudecompHandle_t h, cudecompCommInfo& ci, bool rendezvous, const void* recv_area, const void* output,
                    bool want_direct, hipStream_t stream);
 
+// Two-hop relay of a low-fan-out exchange (plan.h RelayPlan): `world` is the descriptor's communicator of all ranks, `call`
+// the call state begun on IT (peerBegin with the symmetric workspace).  Grows the handle's relay region when needed
+// (collective).  Ordered on `stream`, nothing blocks the host.
+bool peerRelayApplies(cudecompHandle_t h, cudecompGridDesc_t gd, const TransposePlan& plan, cudecompTransposeCommBackend_t backend,
+                      bool inplace);
+void peerRelayEnsureRegion(cudecompHandle_t h, const RelayPlan& rp, int es);
+void peerRelayAlltoall(cudecompHandle_t h, cudecompCommInfo& world, const TransposePlan& plan, const RelayPlan& rp,
+                       const ExchangeBuffers& b, int es, const PeerCall& call, hipStream_t stream);
+
 // All-to-all of the plan's chunks among the members of `ci`.  `stream` carries the pack kernels before and
 // the unpack kernels after; on return the exchange is ordered on `stream`.  `call` = peerBegin's result for the
 // one-sided transport (nullptr for RCCL / MPI).

@@ -101,6 +101,7 @@ bool runAsGraph(cudecompHandle_t h, cudecompGridDesc_t gd, const TransposePlan& 
                 hipStream_t stream) {
   if (!h->graphs_enable || gd->graphs_failed || !plan.exchange) return false;
   if (!(backend == CUDECOMP_TRANSPOSE_COMM_NVSHMEM || backend == CUDECOMP_TRANSPOSE_COMM_NVSHMEM_PL)) return false;
+  if (peerRelayApplies(h, gd, plan, backend, inplace)) return false;  // (the relay allocates on first use; it runs eagerly)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();
@@ -260,6 +261,33 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
   const ExecPath xpath = sm ? PATH_PEER_FUSED : exchangePath(h, ci, backend);
   const bool one_sided = sm || xpath == PATH_PEER_BARRIER;
   PeerCall call;
+  // Two-hop relay (opt-in, CUDECOMP_TWO_HOP_RELAY=1): a low-fan-out exchange of the NVSHMEM enum travels through ALL ranks
+  // of the node, ordered by the flags of the descriptor's communicator of all ranks (plan.h RelayPlan).
+  if (!pipelined && !in_capture && xpath == PATH_PEER_BARRIER && peerRelayApplies(h, gd, plan, backend, inplace)) {
+    auto rit = gd->relay_plans.find(key);
+    if (rit == gd->relay_plans.end()) {
+      TransportTraits traits;
+      traits.pipelined = false;
+      traits.symmetric_recv = true;
+      const auto& hp = std::get<1>(key);
+      rit = gd->relay_plans.emplace(key, buildRelayPlan(gd->shape, h->nranks, h->rank, (TransposeOp)std::get<0>(key), &hp[0], &hp[3],
+                                                        &hp[6], &hp[9], inplace, traits, ci.npergroup)).first;
+    }
+    const RelayPlan& rp = rit->second;
+    if (rp.applies) {
+      peerRelayEnsureRegion(h, rp, es);
+      call = peerBegin(h, gd->world, false, xb.recv, output, false, stream);
+      gd->path_count[xpath]++;
+      gd->relayed++;
+      launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
+      perfMark(pev, 1, stream);
+      peerRelayAlltoall(h, gd->world, plan, rp, xb, es, call, stream);
+      perfMark(pev, 2, stream);
+      launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
+      perfMark(pev, 3, stream);
+      return;
+    }
+  }
   if (one_sided) {
     const bool rendezvous = sm || !transposeBackendIsPeer(backend);
     const bool want_direct = sm && h->direct_put && !inplace && !plan.direct.empty();

@@ -88,6 +88,25 @@ cudecompResult_t cudecompExtPlanTranspose(const cudecompExtGridSpec_t* grid, int
                                           const int32_t input_padding[], const int32_t output_padding[], bool inplace,
                                           int32_t pipelined, int32_t symmetric_recv, int32_t npergroup,
                                           cudecompExtTransposePlan_t* plan);
+/* Two-hop relay of a low-fan-out exchange over all ranks of the node (csrc/plan.h RelayPlan; CUDECOMP_TWO_HOP_RELAY=1): the
+ * relay moves of `rank` for transpose `op` of the decomposition `grid` -- step 1 "scatter" (from the start of my send area)
+ * and step 2 "forward" (from my relay region), each move into the relay region (to_relay = 1, offset in elements) or the
+ * receive area (to_relay = 0, offset relative to the receive area) of GLOBAL rank dst_rank.  applies = 0: the exchange
+ * of this op is not worth relaying (or is local).  Stateless, like cudecompExtPlanTranspose (symmetric_recv = 1 plan). */
+#define CUDECOMP_EXT_MAX_RELAY_MOVES (2 * CUDECOMP_EXT_MAX_MEMBERS * 4)
+typedef struct {
+  int32_t dst_rank, to_relay;
+  int64_t src_off, dst_off, count;
+} cudecompExtRelayMove_t;
+typedef struct {
+  int32_t applies, nranks, slots_per_source, n_scatter, n_forward, reserved;
+  int64_t slot_elements, relay_elements;
+  cudecompExtRelayMove_t scatter[CUDECOMP_EXT_MAX_RELAY_MOVES], forward[CUDECOMP_EXT_MAX_RELAY_MOVES];
+} cudecompExtRelayPlan_t;
+cudecompResult_t cudecompExtPlanRelay(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t op, const int32_t in_halo[],
+                                      const int32_t out_halo[], const int32_t in_pad[], const int32_t out_pad[], bool inplace,
+                                      cudecompExtRelayPlan_t* plan);
+
 cudecompResult_t cudecompExtPlanHalo(const cudecompExtGridSpec_t* grid, int32_t rank, int32_t axis,
                                      const int32_t halo_extents[], const bool halo_periods[], int32_t dim,
                                      const int32_t padding[], int32_t force_packed, cudecompExtHaloPlan_t* plan);
@@ -153,6 +172,8 @@ typedef struct {
    * and the hardware queue slots that GPU has for them: more queues than slots = the driver time-slices every process of
    * the device (ranks sharing a GPU) */
   int64_t compute_queues_on_device, hardware_queue_slots;
+  /* transposes of this descriptor whose exchange went through the two-hop relay (CUDECOMP_TWO_HOP_RELAY=1) */
+  int64_t relayed;
 } cudecompExtCounters_t;
 cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
                                         cudecompExtCounters_t* counters);

@@ -37,7 +37,8 @@ out = {"gpus": int(re.search(r"(\d+) GPU\(s\) listed", plan).group(1)) if re.sea
        "note": ("ranks SHARED one GPU: a flow check of the script, not a measurement" if "shared=1" in plan else
                 "one rank per GPU"),
        "link_matrix": load("02_link_matrix.json"),
-       "multi_device_tests": (text("03_multi_device_tests.log", 600) or "").strip().splitlines()[-4:],
+       "multi_device_tests": [l.strip() for l in (text("03_multi_device_tests.log", 3000) or "").splitlines()
+                              if re.search(r"\b(passed|failed|skipped|error)\b", l)][-3:],
        "bench": {}, "flags_ab": {}, "timeline": None}
 for n in (2, 4, 8):
     rec = load("04_bench_n%d.json" % n)

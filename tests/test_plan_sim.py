@@ -369,3 +369,117 @@ def test_index_maps_reject_bad_arguments():
     bad = cd.make_grid_spec((8, 8, 8), (2, 2), ((0, 1, 1), (0, 1, 2), (0, 1, 2)))
     with pytest.raises(cd.CudecompError):
         cd.cudecompExtPencilInfo(bad, 0, 0)
+
+
+# ---- two-hop relay of low-fan-out exchanges (csrc/plan.h RelayPlan, csrc/transport.cc peerRelayAlltoall) --------------------
+def simulate_relayed_transpose(d, op, halos, pads, inplace):
+    """The relayed exchange on host arrays, rank by rank as the executor orders it: pack; step 1 -- every rank scatters the
+    slices of its chunks into the relay regions of all ranks (two slices per chunk straight into the destination's
+    receive area); step 2 -- every rank forwards what sits in ITS relay region; self chunk; unpack.  Relay regions and
+    receive areas start poisoned, slots must not overlap, and every output pencil must match the analytic oracle.
+    Returns False when the planner says the exchange is not worth relaying."""
+    spec, g = _grids(d)
+    n = g.nranks
+    ai, ao = orc.OP_AXES[op]
+    pa = [g.pencil_info(r, ai, halos[0], pads[0]) for r in range(n)]
+    pb = [g.pencil_info(r, ao, halos[1], pads[1]) for r in range(n)]
+    wsz = g.transpose_workspace_size()
+    plans = [cd.cudecompExtPlanTranspose(spec, r, op, halos[0], halos[1], pads[0], pads[1], inplace, False, True, 0) for r in range(n)]
+    relays = [cd.cudecompExtPlanRelay(spec, r, op, halos[0], halos[1], pads[0], pads[1], inplace) for r in range(n)]
+    assert len({rp.applies for rp in relays}) == 1, "ranks disagree on whether the exchange is relayed"
+    if not relays[0].applies:
+        return False
+    assert len({(rp.slot_elements, rp.relay_elements) for rp in relays}) == 1, "ranks disagree on the relay region's size"
+    bufs, relay = [], []
+    for r in range(n):
+        nel = max(pa[r].size, pb[r].size)
+        a = np.full(nel, -7, dtype=DT)
+        a[:pa[r].size] = g.fill_pencil(pa[r], KIND)
+        b = a if inplace else np.full(nel, -9, dtype=DT)
+        bufs.append([a, b, np.full(wsz, -11, dtype=DT)])
+        relay.append(np.full(relays[r].relay_elements, -13, dtype=DT))
+    for r in range(n):
+        run_moves(plans[r].pack, plans[r].n_pack, bufs[r])
+    written = [np.zeros(relays[r].relay_elements, dtype=bool) for r in range(n)]
+    landed = [np.zeros(bufs[r][plans[r].recv_buf].size, dtype=np.int32) for r in range(n)]
+    # step 1 (all sends read packed data; nothing of step 2 can have happened: it waits for every scatter)
+    for r in range(n):
+        p, rp = plans[r], relays[r]
+        send = bufs[r][p.send_buf]
+        for k in range(rp.n_scatter):
+            m = rp.scatter[k]
+            data = send[p.send_base + m.src_off:p.send_base + m.src_off + m.count].copy()
+            assert data.size == m.count and m.dst_rank != r
+            if m.to_relay:
+                assert not written[m.dst_rank][m.dst_off:m.dst_off + m.count].any(), "relay slots overlap"
+                written[m.dst_rank][m.dst_off:m.dst_off + m.count] = True
+                relay[m.dst_rank][m.dst_off:m.dst_off + m.count] = data
+            else:
+                q = plans[m.dst_rank]
+                off = q.recv_base + m.dst_off
+                bufs[m.dst_rank][q.recv_buf][off:off + m.count] = data
+                landed[m.dst_rank][off:off + m.count] += 1
+    # step 2
+    for r in range(n):
+        rp = relays[r]
+        for k in range(rp.n_forward):
+            m = rp.forward[k]
+            assert not m.to_relay and m.dst_rank != r
+            assert written[r][m.src_off:m.src_off + m.count].all(), "forwarding something nobody sent"
+            q = plans[m.dst_rank]
+            off = q.recv_base + m.dst_off
+            bufs[m.dst_rank][q.recv_buf][off:off + m.count] = relay[r][m.src_off:m.src_off + m.count]
+            landed[m.dst_rank][off:off + m.count] += 1
+    # self chunks, then every element of every remote chunk must have arrived exactly once
+    for r in range(n):
+        p = plans[r]
+        me = p.comm_rank
+        so, ro, c = p.send_base + p.send_off[me], p.recv_base + p.recv_off[me], p.send_cnt[me]
+        bufs[r][p.recv_buf][ro:ro + c] = bufs[r][p.send_buf][so:so + c].copy()
+        for s in range(p.nranks):
+            if s != me:
+                lo = p.recv_base + p.recv_off[s]
+                assert (landed[r][lo:lo + p.recv_cnt[s]] == 1).all(), "a received chunk has holes or double deliveries"
+    for r in range(n):
+        run_moves(plans[r].unpack, plans[r].n_unpack, bufs[r])
+        got = np.ascontiguousarray(bufs[r][1][:pb[r].size])
+        exp = g.fill_pencil(pb[r], KIND)
+        bad = orc.compare_pencil(pb[r], KIND, exp, got, True)
+        assert bad == 0, "rank %d: output pencil wrong at element %d after the relayed exchange" % (r, bad - 1)
+    return True
+
+
+@st.composite
+def relay_decompositions(draw):
+    # grids whose X<->Y or Y<->Z exchange has two members while the node has at least four ranks
+    pdims = draw(st.sampled_from([(2, 2), (2, 4), (4, 2), (2, 3), (3, 2), (2, 5), (2, 6), (6, 2), (2, 8)]))
+    lo = max(pdims)
+    gdims = tuple(draw(st.integers(lo, lo + 9)) for _ in range(3))
+    if draw(st.booleans()):
+        mem_order = tuple(draw(st.sampled_from(PERMS)) for _ in range(3))
+    else:
+        ac = tuple(draw(st.booleans()) for _ in range(3))
+        mem_order = tuple(tuple((ax + i) % 3 if ac[ax] else i for i in range(3)) for ax in range(3))
+    gdims_dist = tuple(draw(st.integers(max(lo, g - 3), g)) for g in gdims) if draw(st.booleans()) else None
+    return {"gdims": gdims, "pdims": pdims, "mem_order": mem_order, "gdims_dist": gdims_dist, "col_major": draw(st.booleans())}
+
+
+@settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
+@given(d=relay_decompositions(), in_halo=small3, out_halo=small3, in_pad=small3, out_pad=small3, inplace=st.booleans())
+def test_relayed_exchange_random_decompositions(d, in_halo, out_halo, in_pad, out_pad, inplace):
+    relayed = 0
+    for op in cd.OPS:
+        relayed += simulate_relayed_transpose(d, op, (in_halo, out_halo), (in_pad, out_pad), inplace)
+    # a two-member exchange on a grid of >= 4 ranks is always relayed: at least the two ops of the 2-wide grid dim
+    assert relayed >= 2, (d["pdims"], relayed)
+
+
+def test_relay_is_not_offered_where_it_cannot_pay():
+    """Slab grids use every link already, two ranks have no relays; an exchange is relayed when it drives at most a third of
+    the links a rank has (plan.h relayWorthwhile): the two-member exchanges of 2x4 / 4x2, every exchange of a 4x4 grid."""
+    zero = (0, 0, 0)
+    for pdims, ops in (((1, 8), ()), ((8, 1), ()), ((2, 1), ()), ((4, 4), tuple(cd.OPS)), ((2, 4), ("XToY", "YToX")), ((4, 2), ("YToZ", "ZToY"))):
+        spec = cd.make_grid_spec((16, 16, 16), pdims, [(0, 1, 2)] * 3)
+        for op in cd.OPS:
+            rp = cd.cudecompExtPlanRelay(spec, 0, op, zero, zero, zero, zero, False)
+            assert bool(rp.applies) == (op in ops), (pdims, op)
