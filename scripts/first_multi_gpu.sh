@@ -17,6 +17,7 @@
 #   4. bench.py --gpus 2 / 4 / 8 as the driver launches it: every candidate under config.also_measured, the xgmi block
 #      with the MEASURED link rate
 #   5. flags in device memory vs the host-pinned board: tiny-transpose latency and the 1024^3 cycle over NVSHMEM_PL
+#   5b. the two-hop relay on the 2 x N/2 pencil grid (BASELINE config 3's grid at N = 8), on and off
 #   6. rocprofv3 kernel + memory-copy timeline of one staged NVSHMEM_PL cycle and one config-5-style halo trio
 #   7. summary -> gpurun_out/first_multi_gpu/summary.json next to the model table of DESIGN.md section 7
 #      (copy it to profiles/r04_scale_<N>gpus.json)
@@ -81,6 +82,15 @@ for flags in 0 1; do
   ( CUDECOMP_FLAGS_IN_DEVICE_MEMORY=$flags timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \
       --master-port 2954$flags bench.py --gpus $n --steps $STEPS --warmup $WARM --size $SIZE --backend peer_pl --pdims 1 $n ) > $OUT/05_bench_peer_pl_flags$flags.log 2>&1
   grep -E '^\{' $OUT/05_bench_peer_pl_flags$flags.log | tail -1 > $OUT/05_bench_peer_pl_flags$flags.json
+done
+
+step "5b two-hop relay on a pencil grid (2 x N/2): NVSHMEM enum with and without CUDECOMP_TWO_HOP_RELAY"
+for relay in 0 1; do
+  n=$MAXR; [ $n -gt 8 ] && n=8
+  [ $n -ge 4 ] || continue
+  ( CUDECOMP_TWO_HOP_RELAY=$relay timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \
+      --master-port 2955$relay bench.py --gpus $n --steps $STEPS --warmup $WARM --size $SIZE --backend peer --pdims 2 $((n / 2)) ) > $OUT/05b_bench_2xN_relay$relay.log 2>&1
+  grep -E '^\{' $OUT/05b_bench_2xN_relay$relay.log | tail -1 > $OUT/05b_bench_2xN_relay$relay.json
 done
 
 step "6 timelines (rocprofv3 kernel + memory-copy trace, no counters)"

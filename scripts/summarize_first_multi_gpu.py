@@ -61,6 +61,13 @@ for flags in (0, 1):
     if rec:
         out["flags_ab"]["nvshmem_pl_cycle_ms_flags_in_%s" % ("device_memory" if flags else "host_board")] = {
             "ms_per_step": rec["ms_per_step"], "pdims": rec["config"]["pdims"], "round_trip_ok": rec["config"].get("round_trip_checksum_ok")}
+out["two_hop_relay"] = {}
+for relay in (0, 1):
+    rec = load("05b_bench_2xN_relay%d.json" % relay)
+    if rec:
+        out["two_hop_relay"]["on" if relay else "off"] = {"ms_per_step": rec["ms_per_step"], "pdims": rec["config"]["pdims"],
+                                                          "per_op_ms": rec["config"].get("per_op_ms"),
+                                                          "round_trip_ok": rec["config"].get("round_trip_checksum_ok")}
 tl = load("06_timeline.json")
 res = tl.get("result") if isinstance(tl, dict) else None
 out["timeline"] = ({k: ("captured: see 06_timeline.json" if isinstance(v, dict) and "error" not in v else v) for k, v in res.items()}
