@@ -29,7 +29,10 @@ def test_runs_in_a_child_of_the_pytest_process(module_state):
 
 
 def test_consecutive_tests_share_the_child(module_state):
-    assert _seen == [os.getpid()] and module_state["alive"]
+    assert module_state["alive"]
+    if os.environ.get("PYTEST_XDIST_WORKER") and not _seen:
+        pytest.skip("xdist dealt the previous test of this module to another worker")
+    assert _seen == [os.getpid()]
 
 
 def test_skips_travel_back():
