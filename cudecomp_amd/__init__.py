@@ -141,7 +141,7 @@ EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecom
                "cudecompExtGetTransposeTimings", "cudecompExtGetHaloTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
                "cudecompExtPlanTranspose", "cudecompExtPlanHalo", "cudecompExtPencilInfo", "cudecompExtShiftedRank",
                "cudecompExtWorkspaceSizes", "cudecompExtGetLinkInfo", "cudecompExtLastKernelName",
-               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs", "cudecompExtTrimWorkspacePool", "cudecompExtPlanRelay"]
+               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs", "cudecompExtTrimWorkspacePool", "cudecompExtPlanRelay", "cudecompExtQueueCensus"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -209,6 +209,7 @@ def lib():
         L.cudecompExtPeerProbe.argtypes = [vp, vp, C.c_size_t, pi32]
         L.cudecompExtGetCounters.argtypes = [vp, vp, C.POINTER(ExtCounters)]
         L.cudecompExtTrimWorkspacePool.argtypes = [vp]
+        L.cudecompExtQueueCensus.argtypes = [vp, pi32, pi32]
         L.cudecompExtPlanTranspose.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, pi32, pi32, C.c_bool, i32,
                                                i32, i32, C.POINTER(ExtTransposePlan)]
         L.cudecompExtPencilInfo.argtypes = [C.POINTER(ExtGridSpec), i32, i32, pi32, pi32, C.POINTER(PencilInfo)]
@@ -446,6 +447,13 @@ def cudecompExtWorkspaceSizes(grid, rank, axis, halo_extents):
     _check(lib().cudecompExtWorkspaceSizes(C.byref(grid), rank, axis, _i3(halo_extents), C.byref(t), C.byref(h)),
            "cudecompExtWorkspaceSizes")
     return t.value, h.value
+
+
+def cudecompExtQueueCensus(handle):
+    """(compute queues of all processes on this process's GPU, its hardware queue slots); (-1, 0) if unreadable."""
+    c, s = C.c_int32(-1), C.c_int32(0)
+    _check(lib().cudecompExtQueueCensus(handle, C.byref(c), C.byref(s)), "cudecompExtQueueCensus")
+    return c.value, s.value
 
 
 def cudecompExtTrimWorkspacePool(handle):

@@ -474,6 +474,9 @@ cudecompResult_t cudecompFinalize(cudecompHandle_t handle) {
       } catch (const Error& e) {
         pending = std::make_unique<Error>(e);
       }
+      // ranks sharing a device: one more look at the device's hardware queues (the first was when the transport came up;
+      // not per call -- reading the driver's tables contends with the other ranks' queue management)
+      if (handle->nranks > 1 && !handle->link_crosses_devices) (void)peerQueueCensus(handle, true);
     }
     delete handle;
     if (pending) throw *pending;
@@ -629,9 +632,7 @@ cudecompResult_t cudecompGridDescDestroy(cudecompHandle_t handle, cudecompGridDe
     if (one_sided) peerCheckStatus(handle);
     // mappings of user buffers their owners have re-created since are kept open on purpose (transport.cc map()); bound them
     peerTrimRetiredImports(handle, 32);
-    // ranks sharing a device: say so (once) when the device's hardware queues are oversubscribed by now
-    if (handle->peer && handle->nranks > 1 && !handle->link_crosses_devices && !handle->queue_warned)
-      (void)peerQueueCensus(handle, true);
+
   }
   CD_API_CATCH()
   return CUDECOMP_RESULT_SUCCESS;

@@ -365,10 +365,26 @@ cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDes
     out->peer_pipelined = gd->path_count[PATH_PEER_PIPELINED];
     out->direct_puts = gd->direct_puts;
     peerPoolCounters(handle, &out->workspace_pool_hits, &out->stale_ipc_mappings, &out->workspace_pool_bytes, &out->retired_imports);
-    int slots = 0;
-    out->compute_queues_on_device = peerQueueCensus(handle, false, &slots);
-    out->hardware_queue_slots = slots;
+    // (the LAST census -- taken when the transport came up or by cudecompExtQueueCensus -- not a fresh one: reading the
+    // driver's tables per call slows ranks that share a device)
+    out->compute_queues_on_device = handle->census_compute_queues;
+    out->hardware_queue_slots = handle->census_queue_slots;
     out->relayed = gd->relayed;
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtQueueCensus(cudecompHandle_t handle, int32_t* compute_queues, int32_t* slots) {
+  try {
+    if (!handle || !handle->initialized) CD_INVALID_USAGE("invalid handle");
+    int s = 0;
+    const int c = peerQueueCensus(handle, false, &s);
+    if (compute_queues) *compute_queues = c;
+    if (slots) *slots = s;
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {
@@ -513,7 +529,7 @@ cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const
     if (force_generic & 4) t.window_mode = 1;  // window kernel whenever the destination rows are off the 64-byte grid
     if (force_generic & 8) t.window_mode = 0;  // never
     if (force_generic & 16) t.tile_shape = 1;  // 4-byte transposes: 128 x 64 tiles
-    if (force_generic & 32) t.tile_shape = 2;  // 4-byte transposes: 64 x 128 tiles
+    if (force_generic & 32) t.tile_shape = 0;  // 4-byte transposes: 64 x 64 tiles (the default is 64 x 128)
     if (force_generic & 64) t.local_store_policy = 2;  // write-through stores (diagnostic policy of section 9)
     if (force_generic & 128) t.xcd_walk = 0;
     KernelStats st;

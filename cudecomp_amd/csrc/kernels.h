@@ -33,8 +33,9 @@ struct KernelTuning {
   int window_mode = -1;            // transposes onto rows off the 64-byte grid: -1 window kernel for moves >= 1 MiB, 0 never, 1 always
   int local_store_policy = -1;     // diagnostic (CUDECOMP_LOCAL_STORE_POLICY): stores of LOCAL moves 0 cached, 1 non-temporal,
                                    // 2 system-scope write-through + wait at the end of the kernel (as remote stores); -1 by size
-  int tile_shape = 0;              // tuning aid (CUDECOMP_TILE_SHAPE): 4-byte transposes with 16-byte lanes use 64 x 64 tiles (0),
-                                   // 128 x 64 (1: 512-byte source segments) or 64 x 128 (2: 512-byte destination segments)
+  int tile_shape = -1;             // 4-byte transposes with 16-byte lanes: 64 x 128 tiles (2: 512-byte destination segments; the
+                                   // default, -1), 64 x 64 (0) or 128 x 64 (1: 512-byte source segments); CUDECOMP_TILE_SHAPE.
+                                   // Measured on the 8-GiB fp32 cycle (profiles/r04_tuning.md): 11.22 / 11.69 / 11.69 ms
   int xcd_walk = 1;                // diagnostic (CUDECOMP_XCD_WALK=0): transposes deal tiles round robin instead of one
                                    // contiguous run of tiles per XCD
 };

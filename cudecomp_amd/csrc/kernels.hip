@@ -754,7 +754,8 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     const bool wide = c.window && es == 8 && vw == 2 && tuning && tuning->window_wide == 1;
     if (wide) c.variant = 102;
     // (4-byte elements, 16-byte lanes, plain kernel: optional 128 x 64 / 64 x 128 tiles -- variants 204 / 304)
-    const int shape = (!c.window && es == 4 && vw == 4 && tuning) ? tuning->tile_shape : 0;
+    int shape = 0;
+    if (!c.window && es == 4 && vw == 4) shape = (tuning && tuning->tile_shape >= 0) ? tuning->tile_shape : 2;
     if (shape == 1) c.variant = 204;
     else if (shape == 2) c.variant = 304;
     const int ti = (es == 16) ? 32 : ((wide || shape == 1) ? 128 : 64);

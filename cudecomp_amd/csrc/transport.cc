@@ -817,40 +817,52 @@ std::vector<std::string> listDir(const std::string& path) {
 }  // namespace
 
 int peerQueueCensus(cudecompHandle_t h, bool warn, int* slots_out) {
-  const std::string root = "/sys/class/kfd/kfd/proc";
-  // the KFD id(s) of the GPU(s) this process has queues on
-  std::vector<std::string> mine;
-  const std::string me = root + "/" + std::to_string((long long)::getpid()) + "/queues";
-  for (const std::string& q : listDir(me)) {
-    std::string id;
-    if (readSmallFile(me + "/" + q + "/gpuid", &id) && std::find(mine.begin(), mine.end(), id) == mine.end()) mine.push_back(id);
+  // Which KFD node is my GPU?  (Not through my pid: inside a container's pid namespace getpid() is not the pid the driver
+  // files my queues under.)  The topology node with my PCI location.
+  if (slots_out) *slots_out = 0;
+  if (h->device < 0) return -1;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), h->device) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
   }
-  if (mine.empty()) return -1;
+  unsigned int dom = 0, b = 0, d = 0, f = 0;
+  if (std::sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return -1;
+  const long long want_loc = ((long long)b << 8) | ((long long)d << 3) | f;
+  std::string my_gpu;
+  int slots = 24;  // hardware queue slots for user compute queues (num_cp_queues; 24 on MI355X) if the node does not say
+  const std::string nodes = "/sys/class/kfd/kfd/topology/nodes";
+  for (const std::string& n : listDir(nodes)) {
+    FILE* fp = std::fopen((nodes + "/" + n + "/properties").c_str(), "r");
+    if (!fp) continue;
+    char key[64];
+    long long val = 0, loc = -1, domain = 0, simd = 0, cpq = 0;
+    while (std::fscanf(fp, "%63s %lld", key, &val) == 2) {
+      if (!std::strcmp(key, "location_id")) loc = val;
+      else if (!std::strcmp(key, "domain")) domain = val;
+      else if (!std::strcmp(key, "simd_count")) simd = val;
+      else if (!std::strcmp(key, "num_cp_queues")) cpq = val;
+    }
+    std::fclose(fp);
+    if (simd <= 0 || loc != want_loc || domain != (long long)dom) continue;
+    if (!readSmallFile(nodes + "/" + n + "/gpu_id", &my_gpu)) my_gpu.clear();
+    if (cpq > 0) slots = (int)cpq;
+    break;
+  }
+  if (my_gpu.empty()) return -1;
+  const std::string root = "/sys/class/kfd/kfd/proc";
   int compute = 0;
   for (const std::string& pid : listDir(root)) {
     const std::string qd = root + "/" + pid + "/queues";
     for (const std::string& q : listDir(qd)) {
       std::string id, type;
-      if (!readSmallFile(qd + "/" + q + "/gpuid", &id) || std::find(mine.begin(), mine.end(), id) == mine.end()) continue;
+      if (!readSmallFile(qd + "/" + q + "/gpuid", &id) || id != my_gpu) continue;
       if (readSmallFile(qd + "/" + q + "/type", &type) && (type == "0" || type == "compute")) ++compute;
     }
   }
-  // hardware queue slots for user compute queues: the topology node of that GPU says (num_cp_queues); 24 on the parts
-  // this was written on when the driver does not
-  int slots = 24;
-  const std::string nodes = "/sys/class/kfd/kfd/topology/nodes";
-  for (const std::string& n : listDir(nodes)) {
-    std::string id;
-    if (!readSmallFile(nodes + "/" + n + "/gpu_id", &id) || id != mine[0]) continue;
-    if (FILE* f = std::fopen((nodes + "/" + n + "/properties").c_str(), "r")) {
-      char key[64];
-      long long val = 0;
-      while (std::fscanf(f, "%63s %lld", key, &val) == 2)
-        if (!std::strcmp(key, "num_cp_queues") && val > 0) slots = (int)val;
-      std::fclose(f);
-    }
-  }
   if (slots_out) *slots_out = slots;
+  h->census_compute_queues = compute;
+  h->census_queue_slots = slots;
   if (warn && compute > slots && !h->queue_warned) {
     h->queue_warned = true;
     fprintf(stderr, "CUDECOMP:WARN: rank %d: the processes sharing this GPU hold %d compute queues, more than its %d hardware queue "

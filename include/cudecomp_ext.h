@@ -168,9 +168,10 @@ typedef struct {
   /* per HANDLE: bytes cudecompFree has parked in the workspace pool right now; IPC mappings of re-created user buffers
    * that are kept open (the newest 32 survive a cudecompGridDescDestroy) */
   int64_t workspace_pool_bytes, retired_imports;
-  /* user compute queues the kernel driver holds on this process's GPU right now, over ALL processes (-1: not readable),
-   * and the hardware queue slots that GPU has for them: more queues than slots = the driver time-slices every process of
-   * the device (ranks sharing a GPU) */
+  /* user compute queues the kernel driver held on this process's GPU at the LAST census (when the one-sided transport
+   * came up, at cudecompExtQueueCensus), over ALL processes (-1: none taken / not readable), and the hardware queue slots
+   * that GPU has for them: more queues than slots = the driver time-slices every process of the device (ranks sharing a
+   * GPU) */
   int64_t compute_queues_on_device, hardware_queue_slots;
   /* transposes of this descriptor whose exchange went through the two-hop relay (CUDECOMP_TWO_HOP_RELAY=1) */
   int64_t relayed;
@@ -184,6 +185,10 @@ cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDes
  * cudecompMalloc that runs out of memory releases the pool by itself and retries; an APPLICATION that needs the memory
  * for its own allocations calls this.  Collective over the handle's communicator. */
 cudecompResult_t cudecompExtTrimWorkspacePool(cudecompHandle_t handle);
+
+/* A fresh census of the compute queues all processes hold on this process's GPU and of its hardware queue slots (from the
+ * kernel driver's tables; -1 / 0 if they cannot be read).  Local, but not free: do not call it per operation. */
+cudecompResult_t cudecompExtQueueCensus(cudecompHandle_t handle, int32_t* compute_queues, int32_t* hardware_queue_slots);
 
 /* One-direction copy rate from this rank to the next rank of the node, measured when the one-sided transport came up
  * (64 MiB, both engines, slowest rank): gbps_sdma through hipMemcpyAsync (copy engines), gbps_cu through the library's
@@ -210,7 +215,7 @@ cudecompResult_t cudecompExtEstimateCycleMs(cudecompHandle_t handle, const cudec
  * force_generic is a bit mask: 1 selects the element-wise fallback kernel, 2 forces the streaming
  * (non-temporal) variants that are normally used only for moves of 32 MiB and more, 4 selects the window variant of
  * the LDS transpose for every destination off the 64-byte grid (normally only for moves of 1 MiB and more), 8 disables
- * it; 16 / 32: 128 x 64 / 64 x 128 tiles for 4-byte transposes (tuning variants); 64: write-through stores, 128:
+ * it; 16 / 32: 128 x 64 / 64 x 64 tiles for 4-byte transposes (tuning variants; the default is 64 x 128); 64: write-through stores, 128:
  * round-robin tile walk (diagnostic variants).  *kernel_class (optional) receives the
  * kernel flavour used: 0 rows, 1 LDS transpose, 2 generic. */
 cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const int64_t extent[3],

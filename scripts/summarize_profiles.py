@@ -35,6 +35,39 @@ for layout in ("contiguous", "default"):
                               "FETCH_SIZE_KB_mean_per_dispatch": fk, "WRITE_SIZE_KB_mean_per_dispatch": wk,
                               "hbm_read_bytes_per_launch_corrected": rd, "hbm_write_bytes_per_launch": wr,
                               "hbm_traffic_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": 2 * 1024 ** 3 * 8}
+# the other element types at the benchmark's pencil size (scripts/gpu_profile_dtypes.sh), when that pass was run
+import os
+out["dtypes"] = {}
+for dt, es in (("fp32", 4), ("complex128", 16)):
+    stats = "gpurun_out/prof/dtype_%s_trace/bench_kernel_stats.csv" % dt
+    if not os.path.exists(stats):
+        continue
+    rows = list(csv.DictReader(open(stats)))
+    ks = [r for r in rows if "transpose_kernel" in r["Name"]]
+    if not ks:
+        continue
+    k = ks[0]
+
+    def dmean(kind, counter):
+        try:
+            for r in csv.DictReader(open("gpurun_out/prof/dtype_%s_%s/bench_counter_summary.csv" % (dt, kind))):
+                if r["kernel"] == k["Name"] and r["counter"] == counter:
+                    return float(r["mean_per_dispatch"])
+        except OSError:
+            pass
+        return None
+
+    fk, wk = dmean("fetch", "FETCH_SIZE"), dmean("write", "WRITE_SIZE")
+    alg = 2 * 8 * 1024 ** 3
+    rec = {"kernel": k["Name"], "calls": int(k["Calls"]), "avg_ns": float(k["AverageNs"]),
+           "achieved_GBps": round(alg / float(k["AverageNs"]), 1), "frac_of_8TBps": round(alg / float(k["AverageNs"]) / 8000.0, 4),
+           "algorithmic_bytes_per_launch": alg, "workload": "8-GiB pencil, 1x1 grid, axis-contiguous layout, out of place "
+           "(scripts/probe/dtype_table.py %s)" % dt}
+    if fk is not None and wk is not None:
+        rec.update({"FETCH_SIZE_KB_mean_per_dispatch": fk, "WRITE_SIZE_KB_mean_per_dispatch": wk,
+                    "hbm_traffic_bytes_per_launch": fk * 1024 * 2 + wk * 1024,
+                    "traffic_over_algorithmic": round((fk * 1024 * 2 + wk * 1024) / alg, 4)})
+    out["dtypes"][dt] = rec
 json.dump(out, open("profiles/%s_pmc_summary.json" % rnd, "w"), indent=1)
 print(json.dumps({k: (v["kernel"].split("::")[-1], round(v["avg_ns"] / 1e6, 4), v["hbm_traffic_bytes_per_launch"])
                   for k, v in out["layouts"].items()}, indent=1))

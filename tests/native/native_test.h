@@ -153,8 +153,12 @@ inline void notePaths(cudecompHandle_t handle, cudecompGridDesc_t gdesc) {
   cudecompExtCounters_t c;
   if (cudecompExtGetCounters(handle, gdesc, &c) != CUDECOMP_RESULT_SUCCESS) return;
   mpiPathTransposes() += c.mpi;
-  if (c.compute_queues_on_device > queueCensus()[0]) queueCensus()[0] = c.compute_queues_on_device;
-  queueCensus()[1] = c.hardware_queue_slots;
+}
+inline void noteQueues(cudecompHandle_t handle) {  // a fresh census: not per case (it is not free), see nativeMain
+  int32_t c = -1, s = 0;
+  if (cudecompExtQueueCensus(handle, &c, &s) != CUDECOMP_RESULT_SUCCESS) return;
+  if (c > queueCensus()[0]) queueCensus()[0] = c;
+  queueCensus()[1] = s;
 }
 
 // Verdict of a case over all ranks without MPI: every rank drops a one-byte file into a job directory under /dev/shm,
@@ -443,6 +447,7 @@ int nativeMain(int argc, char** argv, RunCase run_case) {
       fprintf(stderr, "rank %d: %s\n", rank, e.what());
     }
     any_local_failure |= res;
+    if (rank == 0 && (res || i == cases.size() / 2)) noteQueues(handle);  // at failures, and once while everybody is busy
     res = reduceVerdict(res, (int)i);
     if (rank == 0) {
       if (from_file) printf(res ? " FAILED\n" : " PASSED\n");
