@@ -411,7 +411,9 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     if (const char* v = std::getenv("CUDECOMP_RCCL_NATIVE_ALLTOALL")) h->rccl_native_alltoall = std::strtol(v, nullptr, 10) != 0;
     h->direct_put = !envIsOne("CUDECOMP_DISABLE_DIRECT_PUT");
     h->two_hop_relay = envIsOne("CUDECOMP_TWO_HOP_RELAY");
+    if (const char* v = std::getenv("CUDECOMP_FUSE_SMALL_EXCHANGES_KIB")) h->fuse_small_bytes = std::strtoll(v, nullptr, 10) << 10;
     h->debug_verify_exchange = envIsOne("CUDECOMP_DEBUG_VERIFY_EXCHANGE");
+    if (h->debug_verify_exchange) h->fuse_small_bytes = 0;  // (the verification checksums the send area, which a fused put never fills)
     if (const char* v = std::getenv("CUDECOMP_PIPELINE_MIN_STAGE_MIB")) h->pipeline_min_stage_bytes = std::strtoll(v, nullptr, 10) << 20;
     if (const char* v = std::getenv("CUDECOMP_PIPELINE_STAGES")) {
       const long k = std::strtol(v, nullptr, 10);

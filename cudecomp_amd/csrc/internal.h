@@ -71,6 +71,8 @@ struct cudecompHandle {
   std::string performance_report_write_dir;   // CSV output directory ("" = none)
   bool col_major_env_warned = false;
   bool ipc_warned = false;
+  long long fuse_small_bytes = 1ll << 20;  // CUDECOMP_FUSE_SMALL_EXCHANGES_KIB: NVSHMEM-enum exchanges of pencils up to this size
+                                           // run as a fused pack + put on one stream (0 = never)
   bool two_hop_relay = false;         // CUDECOMP_TWO_HOP_RELAY=1: low-fan-out exchanges of the NVSHMEM enum travel through all ranks of the node
   void* relay_buf = nullptr;          // my relay region (a library region mapped into every rank), grown on demand
   size_t relay_bytes = 0;

@@ -305,6 +305,20 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
     perfMark(pev, 3, stream);
     return;
   }
+  if (!pipelined && xpath == PATH_PEER_BARRIER && transposeBackendIsPeer(backend) && !h->self_exchange &&
+      plan.pencil_elements_a * es <= h->fuse_small_bytes) {
+    // Small exchanges of the NVSHMEM enum are latency-bound: eight launches and two cross-stream hand-offs (pack, ready wait,
+    // copy kernel on the copy stream, signal, self copy, landed wait, unpack) against six launches on ONE stream when the
+    // pack kernel stores straight into the peers' receive areas, as NVSHMEM_SM does (16^3 fp64 on 2 / 4 ranks: 66-113 us ->
+    // the fused put's 14-19 us, profiles/r04_flags_latency.json).  Same contract (symmetric workspace), same result.
+    gd->path_count[xpath]++;
+    perfMark(pev, 1, stream);
+    peerPutExchange(h, ci, plan, bufs, es, call, stream);
+    perfMark(pev, 2, stream);
+    launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
+    perfMark(pev, 3, stream);
+    return;
+  }
   if (!pipelined) {
     gd->path_count[xpath]++;
     launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
