@@ -447,7 +447,7 @@ def extras_single_gpu(cd, torch, h, stream):
     return out
 
 
-def dtype_table(cd, torch, h, stream):
+def dtype_table(cd, torch, h, stream, only=None):
     """The other three element types the reference instantiates (src/cudecomp_kernels.cu:29-46; its published sweeps
     are float and double) at the benchmark's pencil size: 8-GiB pencils on a 1x1 grid, out of place, both layouts,
     2 warm-up + 5 timed cycles with HIP events around every transpose.  Per hop: ms, achieved GB/s = 2 x pencil bytes / ms,
@@ -456,6 +456,8 @@ def dtype_table(cd, torch, h, stream):
     cases = [("fp32", cd.FLOAT, 4, (2048, 1024, 1024)), ("complex64", cd.FLOAT_COMPLEX, 8, (1024, 1024, 1024)),
              ("complex128", cd.DOUBLE_COMPLEX, 16, (1024, 1024, 512))]
     for name, dt, es, gdims in cases:
+        if only and name not in only:
+            continue
         for layout, ac in (("contiguous", (1, 1, 1)), ("default", (0, 0, 0))):
             row = {"dtype": name, "element_bytes": es, "gdims": list(gdims), "layout": layout}
             try:
@@ -486,8 +488,8 @@ def dtype_table(cd, torch, h, stream):
                 for op in cd.OPS:
                     avg = sum(ms[op]) / len(ms[op])
                     gbps = 2 * nbytes / (avg * 1e-3) / 1e9
-                    per_op.append({"op": op, "ms": round(avg, 4), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                                   "kernel": kernels[op]})
+                    per_op.append({"op": op, "ms": round(avg, 4), "ms_min": round(min(ms[op]), 4), "ms_max": round(max(ms[op]), 4),
+                                   "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "kernel": kernels[op]})
                 row["per_op"] = per_op
                 row["cycle_ms"] = round(sum(o["ms"] for o in per_op), 4)
                 row["min_frac"] = min(o["frac"] for o in per_op)

@@ -14,11 +14,11 @@ import cudecomp_amd as cd  # noqa: E402
 
 torch.zeros(1, device="cuda")
 h = cd.cudecompInit()
-t = bench.dtype_table(cd, torch, h, torch.cuda.current_stream().cuda_stream)
 want = sys.argv[1:]
+t = bench.dtype_table(cd, torch, h, torch.cuda.current_stream().cuda_stream, only=want or None)
 for row in t["rows"]:
     if want and row["dtype"] not in want:
         continue
     print(json.dumps({k: row.get(k) for k in ("dtype", "layout", "cycle_ms", "min_frac", "round_trip_ok", "error")}
-                     | {"per_op": [(o["op"], o["ms"], o["frac"], o["kernel"]) for o in row.get("per_op", [])]}))
+                     | {"per_op": [(o["op"], o["ms"], o["ms_min"], o["ms_max"], o["frac"], o["kernel"]) for o in row.get("per_op", [])]}))
 cd.cudecompFinalize(h)
