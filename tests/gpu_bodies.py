@@ -732,6 +732,15 @@ def pool_pressure(rank, nranks, args):
     return out
 
 
+def queue_census(rank, nranks, args):
+    """The library's census of the compute queues on its GPU (cudecompExtQueueCensus) after a cycle on every rank."""
+    r = cycle_exact(rank, nranks, args)
+    h = _handle(rank)
+    torch.cuda.synchronize()
+    compute, slots = cd.cudecompExtQueueCensus(h)
+    return {"failures": r["failures"], "compute": compute, "slots": slots}
+
+
 def halo_timed(rank, nranks, args):
     """cudecompUpdateHalos{X,Y,Z} timing per pencil axis and dim on a multi-rank grid (BASELINE config 5 when called with
     its sizes): K timed updates per dim bracketed by device events, and the library's own per-phase samples (pack /
