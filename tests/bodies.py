@@ -144,6 +144,58 @@ def staged_exchange_gloo(plan, bufs, stages, rank, itemsize, dt):
         run_moves(moves, plan.n_unpack, bufs)
 
 
+def relayed_exchange_gloo(plan, relays, bufs, rank, nranks, itemsize, dt):
+    """The two-hop relay (csrc/plan.h RelayPlan, csrc/transport.cc peerRelayAlltoall) with a real multi-process exchange: every
+    rank derives the relay moves of ALL ranks from the stateless planner (as the library does), so a receiver knows what
+    each sender will send it in either step and in which order.  Step 1 scatters my slices (relay slots of the other ranks /
+    two direct slices per chunk), step 2 forwards what landed in MY relay region; relay region and receive area start
+    poisoned."""
+    import torch
+    import torch.distributed as dist
+    mine = relays[rank]
+    sendb, recvb = bufs[plan.send_buf], bufs[plan.recv_buf]
+    relay = np.full(max(mine.relay_elements, 1), -777, dtype=dt)
+    P = plan.nranks
+    lo = plan.recv_base + min(plan.recv_off[i] for i in range(P))
+    hi = plan.recv_base + max(plan.recv_off[i] + plan.recv_cnt[i] for i in range(P))
+    me = plan.comm_rank
+    self_chunk = sendb[plan.send_base + plan.send_off[me]:plan.send_base + plan.send_off[me] + plan.send_cnt[me]].copy()
+    if plan.recv_buf == 2:
+        recvb[lo:hi] = -12345
+
+    def step(which, src_buf, src_base):
+        reqs, landing = [], []
+        for s in range(nranks):  # what the others send me, in the order they send it
+            if s == rank:
+                continue
+            moves = getattr(relays[s], which)
+            for k in range(getattr(relays[s], "n_" + which)):
+                m = moves[k]
+                if m.dst_rank == rank and m.count:
+                    t = torch.zeros(m.count * itemsize, dtype=torch.uint8)
+                    reqs.append(dist.irecv(t, s))
+                    landing.append((t, bool(m.to_relay), m.dst_off, m.count))
+        moves = getattr(mine, which)
+        for k in range(getattr(mine, "n_" + which)):
+            m = moves[k]
+            assert m.dst_rank != rank
+            data = np.ascontiguousarray(src_buf[src_base + m.src_off:src_base + m.src_off + m.count])
+            assert data.size == m.count
+            reqs.append(dist.isend(torch.from_numpy(data.view(np.uint8).copy()), m.dst_rank))
+        for q in reqs:
+            q.wait()
+        for t, to_relay, off, cnt in landing:
+            if to_relay:
+                relay[off:off + cnt] = t.numpy().view(dt)
+            else:
+                recvb[plan.recv_base + off:plan.recv_base + off + cnt] = t.numpy().view(dt)
+
+    step("scatter", sendb, plan.send_base)
+    dist.barrier()  # (the library: wait "step 1 of everybody has landed")
+    step("forward", relay, 0)
+    recvb[plan.recv_base + plan.recv_off[me]:plan.recv_base + plan.recv_off[me] + plan.recv_cnt[me]] = self_chunk
+
+
 def plan_transpose_gloo(rank, nranks, args):
     """Execute the product's transpose plans with numpy + gloo send/recv and check them against the analytic
     oracle, for a full X->Y->Z->Y->X chain (tests/cc/transpose_test.cc:516-559)."""
@@ -165,6 +217,7 @@ def plan_transpose_gloo(rank, nranks, args):
     assert wsz == g.transpose_workspace_size()
     nel = max(p.size for p in pin)
     failures = []
+    relayed = {"n": 0}
     for backend in args.get("backends", [cd.TRANSPOSE_COMM_NCCL]):
         for oop in (True, False):
             a = np.zeros(nel, dtype=dt)
@@ -177,6 +230,25 @@ def plan_transpose_gloo(rank, nranks, args):
                 plan = cd.cudecompExtGetTransposePlan(h, gd, op, halos[ai], halos[ao], pads[ai], pads[ao],
                                                       inplace=not oop, backend_override=backend)
                 bufs = [cur, nxt, work]
+                if args.get("relay") and not plan.noop and plan.exchange:
+                    mo = args.get("mem_order") or tuple(tuple((ax + i) % 3 if args.get("ac", (0, 0, 0))[ax] else i for i in range(3))
+                                                        for ax in range(3))
+                    spec = cd.make_grid_spec(args["gdims"], args["pdims"], mo, args.get("gdims_dist"), args.get("rank_order", 0) == 2)
+                    relays = [cd.cudecompExtPlanRelay(spec, r, op, halos[ai], halos[ao], pads[ai], pads[ao], not oop)
+                              for r in range(nranks)]
+                    if relays[rank].applies:
+                        relayed["n"] += 1
+                        run_moves(plan.pack, plan.n_pack, bufs)
+                        relayed_exchange_gloo(plan, relays, bufs, rank, nranks, a.itemsize, dt)
+                        run_moves(plan.unpack, plan.n_unpack, bufs)
+                        exp = g.fill_pencil(opin[ao], kind)
+                        got = np.ascontiguousarray(nxt[:pin[ao].size])
+                        bad = orc.compare_pencil(opin[ao], kind, exp, got, True)
+                        if bad:
+                            failures.append("relayed, oop %s %s: mismatch at %d" % (oop, op, bad - 1))
+                        if oop:
+                            cur, nxt = nxt, cur
+                        continue
                 staged = args.get("stages", 0) > 1 and backend in (cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_MPI_P2P_PL)
                 if not plan.noop and plan.exchange and staged:
                     staged_exchange_gloo(plan, bufs, args["stages"], rank, a.itemsize, dt)
@@ -231,4 +303,6 @@ def plan_transpose_gloo(rank, nranks, args):
     cd.cudecompGridDescDestroy(h, gd)
     cd.cudecompFinalize(h)
     dist.destroy_process_group()
+    if args.get("relay") and relayed["n"] < args.get("expect_relayed", 1):
+        failures.append("only %d exchanges were relayed, expected at least %d" % (relayed["n"], args.get("expect_relayed", 1)))
     return failures

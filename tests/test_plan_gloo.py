@@ -63,3 +63,17 @@ def test_staged_pipeline_over_gloo(nranks, pdims, stages):
             args.update({"halos": halos, "pads": pads})
         for failures in run_ranks(nranks, "tests.bodies", "plan_transpose_gloo", args):
             assert failures == []
+
+
+@pytest.mark.parametrize("nranks,pdims,per_cycle", [(4, (2, 2), 4), (6, (2, 3), 2), (6, (3, 2), 2)])
+def test_two_hop_relay_over_gloo(nranks, pdims, per_cycle):
+    """The two-hop relay of two-member exchanges (CUDECOMP_TWO_HOP_RELAY; csrc/plan.h RelayPlan) on 4 and 6 processes: the
+    scatter / forward moves of the stateless planner travel over gloo, relay region and receive area start poisoned, every
+    hop of the cycle is compared with the analytic oracle, in and out of place, with halos and padding."""
+    for ac, halos, pads in (((1, 1, 1), None, None), ((0, 0, 0), [K.IN_HALO, K.OUT_HALO, K.IN_HALO], [K.IN_PAD, K.OUT_PAD, K.IN_PAD])):
+        args = {"gdims": (13, 12, 14), "pdims": pdims, "ac": ac, "kind": 1, "relay": True, "expect_relayed": 2 * per_cycle,
+                "backends": [cd.TRANSPOSE_COMM_NVSHMEM]}
+        if halos:
+            args.update({"halos": halos, "pads": pads})
+        for failures in run_ranks(nranks, "tests.bodies", "plan_transpose_gloo", args):
+            assert failures == []
