@@ -450,7 +450,7 @@ def extras_single_gpu(cd, torch, h, stream):
 def dtype_table(cd, torch, h, stream, only=None):
     """The other three element types the reference instantiates (src/cudecomp_kernels.cu:29-46; its published sweeps
     are float and double) at the benchmark's pencil size: 8-GiB pencils on a 1x1 grid, out of place, both layouts,
-    2 warm-up + 5 timed cycles with HIP events around every transpose.  Per hop: ms, achieved GB/s = 2 x pencil bytes / ms,
+    2 warm-up + 5 timed cycles with HIP events around every transpose.  Per hop: ms (median; min / max beside it), achieved GB/s = 2 x pencil bytes / ms,
     fraction of the 8 TB/s HBM peak and the kernel the library launched for it."""
     rows = []
     cases = [("fp32", cd.FLOAT, 4, (2048, 1024, 1024)), ("complex64", cd.FLOAT_COMPLEX, 8, (1024, 1024, 1024)),
@@ -486,7 +486,7 @@ def dtype_table(cd, torch, h, stream, only=None):
                 row["round_trip_ok"] = bool(torch.equal(a, keep))
                 per_op = []
                 for op in cd.OPS:
-                    avg = sum(ms[op]) / len(ms[op])
+                    avg = sorted(ms[op])[len(ms[op]) // 2]  # median of the timed cycles (one hiccup in five must not halve a rate)
                     gbps = 2 * nbytes / (avg * 1e-3) / 1e9
                     per_op.append({"op": op, "ms": round(avg, 4), "ms_min": round(min(ms[op]), 4), "ms_max": round(max(ms[op]), 4),
                                    "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "kernel": kernels[op]})
@@ -501,7 +501,7 @@ def dtype_table(cd, torch, h, stream, only=None):
                 row["error"] = str(e)[:200]
             rows.append(row)
     return {"workload": "X->Y->Z->Y->X cycle of an 8-GiB pencil per element type, 1x1 grid, out of place, 2 warm-up + 5 timed "
-                        "cycles, HIP events around every transpose; frac = 2 x pencil bytes / ms / 8 TB/s", "rows": rows}
+                        "cycles, HIP events around every transpose; ms = median per hop; frac = 2 x pencil bytes / ms / 8 TB/s", "rows": rows}
 
 
 # ---------------------------------------------------------------------------------------------------------------
