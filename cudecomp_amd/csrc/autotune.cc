@@ -277,12 +277,20 @@ double estimateTransposeCycleMs(cudecompHandle_t h, const GridShape& g, int es, 
     } catch (const Error&) {
       passes = 2;  // (an unsupported candidate is rejected elsewhere; keep the ordering total)
     }
-    const double local = passes * 2.0 * pencil / hbm;
+    double local = passes * 2.0 * pencil / hbm;
     double comm = 0;
     if (P > 1) {
       const double chunk = pencil / P;
       const bool on_node = P <= h->local_nranks;
       comm = on_node ? chunk / link : chunk * (P - 1) / nic;
+      // two-hop relay (CUDECOMP_TWO_HOP_RELAY=1, NVSHMEM enum; plan.h): every chunk travels as one slice per rank of the
+      // node, the busiest link carries two slices per direction, and the relayed share of the bytes makes one extra HBM
+      // round trip at the relays
+      const int n = g.pdims[0] * g.pdims[1];
+      if (h->two_hop_relay && backend == CUDECOMP_TRANSPOSE_COMM_NVSHMEM && on_node && n <= h->local_nranks && relayWorthwhile(P, n)) {
+        comm = 2.0 * (P - 1) * chunk / n / link;
+        local += 2.0 * (P - 1) * chunk * (n - 2) / n / hbm;
+      }
     }
     if (fused && P > 1) total += std::max(comm, 2.0 * pencil / hbm) + (passes > 1 ? 2.0 * pencil / hbm : 0.0);  // the put IS the pack
     else if (staged) total += std::max(local, comm) + std::min(local, comm) / std::max(1, staged_k);
