@@ -1,0 +1,43 @@
+"""Per-case speed of the native test programs: the round-3 build (scripts/probe/ab_r03, built from commit cc346f8) against
+HEAD on the SAME box, alternating, 4 ranks, a slice of the reference's transpose_test_cc case list (all eight backends need
+the RCCL stand-in, so only the one-sided enums 1, 2, 3, 6, 7, 8 are taken).  Prints seconds per launch and ms per case."""
+import os
+import re
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests.mp import run_binary_ranks  # noqa: E402
+from tests.test_gpu_runner_cases import load_cases  # noqa: E402
+
+lines = [l for l in load_cases()["transpose_test_cc"] if re.search(r"--backend [123678] ", l)][::3][:400]
+only = {k: [l for l in lines if "--backend %d " % k in l][:120] for k in (1, 6, 8)}
+builds = [("r03", os.path.join(ROOT, "scripts", "probe", "ab_r03", "tests", "native", "build", "transpose_test_R32")),
+          ("head", os.path.join(ROOT, "tests", "native", "build", "transpose_test_R32"))]
+
+
+def run(label, exe, cases, env=None):
+    with tempfile.NamedTemporaryFile("w", suffix="_cases.txt", delete=False) as f:
+        f.write("\n".join(cases) + "\n")
+        path = f.name
+    t0 = time.time()
+    logs = run_binary_ranks(4, [exe, "--testfile", path], timeout=900, extra_env=env)
+    wall = time.time() - t0
+    os.unlink(path)
+    m = re.search(r"Completed all tests, running time ([0-9.]+) s", logs[0])
+    ok = logs[0].count(" PASSED") == len(cases)
+    print("%-28s %4d cases  wall %6.1f s  in-program %6.1f s  %6.1f ms per case  %s" % (label, len(cases), wall, float(m.group(1)) if m else -1,
+          1000 * float(m.group(1)) / len(cases) if m else -1, "ok" if ok else "FAILED"), flush=True)
+
+
+for rep in range(2):
+    for label, exe in builds:
+        run("%s all backends" % label, exe, lines)
+for b, cases in only.items():
+    for label, exe in builds:
+        run("%s backend %d" % (label, b), exe, cases)
+run("head, small exchanges not fused", builds[1][1], lines, {"CUDECOMP_FUSE_SMALL_EXCHANGES_KIB": "0"})
+run("head, no workspace pool", builds[1][1], lines, {"CUDECOMP_WORKSPACE_POOL_MIB": "0"})
+run("r03, no workspace pool", builds[0][1], lines, {"CUDECOMP_WORKSPACE_POOL_MIB": "0"})
