@@ -751,13 +751,21 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     // share of overlap rows)
     // (window kernel, 8-byte elements, optional: 128 x 64 tiles with 512 threads -- 1-KiB source segments span nine
     // lines instead of 2 x five; variant 102)
+#ifdef CUDECOMP_TUNING_VARIANTS
     const bool wide = c.window && es == 8 && vw == 2 && tuning && tuning->window_wide == 1;
+#else
+    const bool wide = false;  // (the 128 x 64 / 512-thread window variant exists in tuning builds only)
+#endif
     if (wide) c.variant = 102;
     // (4-byte elements, 16-byte lanes, plain kernel: optional 128 x 64 / 64 x 128 tiles -- variants 204 / 304)
     int shape = 0;
-    if (!c.window && es == 4 && vw == 4) shape = (tuning && tuning->tile_shape >= 0) ? tuning->tile_shape : 2;
+    if (!c.window && es == 4 && vw == 4) shape = 2;
+#ifdef CUDECOMP_TUNING_VARIANTS
+    if (!c.window && es == 4 && vw == 4 && tuning && tuning->tile_shape >= 0) shape = tuning->tile_shape;
+#endif
     if (shape == 1) c.variant = 204;
     else if (shape == 2) c.variant = 304;
+    // (shape 0 keeps variant 4 = 64 x 64 tiles: only in builds with CUDECOMP_TUNING_VARIANTS)
     const int ti = (es == 16) ? 32 : ((wide || shape == 1) ? 128 : 64);
     const int tj = ((c.window && es == 4) || shape == 2) ? 128 : ((es == 16) ? 32 : 64);
     c.t0 = (unsigned int)((c.dm.e[0] + ti - 1) / ti);
@@ -788,8 +796,11 @@ void launchWindowT(int variant, int es, const Batch& b, unsigned int blocks, hip
     if (variant == 4) transpose_window_kernel<4, 4, 64, 128, STREAM><<<grid, block, 0, stream>>>(b);
     else transpose_window_kernel<4, 1, 64, 128, STREAM><<<grid, block, 0, stream>>>(b);
   } else if (es == 8) {
+#ifdef CUDECOMP_TUNING_VARIANTS
     if (variant == 2 && wide) transpose_window_kernel<8, 2, 128, 64, STREAM, 512><<<grid, dim3(512), 0, stream>>>(b);
-    else if (variant == 2) transpose_window_kernel<8, 2, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
+    else
+#endif
+    if (variant == 2) transpose_window_kernel<8, 2, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
     else transpose_window_kernel<8, 1, 64, 64, STREAM><<<grid, block, 0, stream>>>(b);
   } else {
     transpose_window_kernel<16, 1, 32, 32, STREAM><<<grid, block, 0, stream>>>(b);
@@ -813,9 +824,12 @@ void launchBatchT(MoveClass cls, int variant, int es, const Batch& b, unsigned i
       break;
     case MOVE_TRANSPOSE:
       if (es == 4) {
+#ifdef CUDECOMP_TUNING_VARIANTS  // tuning builds only (make TUNING_VARIANTS=1): the 64 x 64 and 128 x 64 tiles of the A/B
         if (variant == 204) transpose_kernel<4, 4, 128, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
-        else if (variant == 304) transpose_kernel<4, 4, 64, 128, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
         else if (variant == 4) transpose_kernel<4, 4, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
+        else
+#endif
+        if (variant == 304) transpose_kernel<4, 4, 64, 128, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
         else transpose_kernel<4, 1, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
       } else if (es == 8) {
         if (variant == 2) transpose_kernel<8, 2, 64, 64, STREAM, SWZ><<<grid, block, 0, stream>>>(b);
@@ -862,15 +876,21 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
     else launchBatchT<4, false>(cls, variant, es, b, blocks, stream, window);
     return;
   }
+  // (mode 1 -- non-temporal loads, cached stores -- is a tuning mode of the transposes: its instantiations exist in tuning
+  // builds only; row copies reach their streaming kernels through mode 2)
   if (swizzle) {
     if (stream_access == 3) launchBatchT<3, true>(cls, variant, es, b, blocks, stream, window);
     else if (stream_access == 2) launchBatchT<2, true>(cls, variant, es, b, blocks, stream, window);
+#ifdef CUDECOMP_TUNING_VARIANTS
     else if (stream_access == 1) launchBatchT<1, true>(cls, variant, es, b, blocks, stream, window);
+#endif
     else launchBatchT<0, true>(cls, variant, es, b, blocks, stream, window);
   } else {
     if (stream_access == 3) launchBatchT<3, false>(cls, variant, es, b, blocks, stream, window);
     else if (stream_access == 2) launchBatchT<2, false>(cls, variant, es, b, blocks, stream, window);
+#ifdef CUDECOMP_TUNING_VARIANTS
     else if (stream_access == 1) launchBatchT<1, false>(cls, variant, es, b, blocks, stream, window);
+#endif
     else launchBatchT<0, false>(cls, variant, es, b, blocks, stream, window);
   }
 }

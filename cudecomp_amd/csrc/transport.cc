@@ -1036,7 +1036,8 @@ void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
     h->peer->agreePoolLimit();
     if (!h->boot->allreduceOr(!have_dev)) h->peer->setupDeviceFlags();  // (geometry-only jobs have no device)
     peerMeasureLink(h);
-    if (h->nranks > 1 && !h->link_crosses_devices && have_dev) (void)peerQueueCensus(h, true);  // ranks share a device
+    if (h->nranks > 1 && !h->link_crosses_devices && have_dev && !std::getenv("CUDECOMP_SKIP_QUEUE_CENSUS"))
+      (void)peerQueueCensus(h, true);  // ranks share a device
   }
 }
 

@@ -26,18 +26,18 @@ def run(label, exe, cases, env=None):
     logs = run_binary_ranks(4, [exe, "--testfile", path], timeout=900, extra_env=env)
     wall = time.time() - t0
     os.unlink(path)
+    for l in logs[0].splitlines():
+        if l.startswith("Phase times") or "DEBUG destroy timing" in l:
+            print("    " + l, flush=True)
     m = re.search(r"Completed all tests, running time ([0-9.]+) s", logs[0])
     ok = logs[0].count(" PASSED") == len(cases)
     print("%-28s %4d cases  wall %6.1f s  in-program %6.1f s  %6.1f ms per case  %s" % (label, len(cases), wall, float(m.group(1)) if m else -1,
           1000 * float(m.group(1)) / len(cases) if m else -1, "ok" if ok else "FAILED"), flush=True)
 
 
-for rep in range(2):
-    for label, exe in builds:
-        run("%s all backends" % label, exe, lines)
-for b, cases in only.items():
-    for label, exe in builds:
-        run("%s backend %d" % (label, b), exe, cases)
-run("head, small exchanges not fused", builds[1][1], lines, {"CUDECOMP_FUSE_SMALL_EXCHANGES_KIB": "0"})
-run("head, no workspace pool", builds[1][1], lines, {"CUDECOMP_WORKSPACE_POOL_MIB": "0"})
-run("r03, no workspace pool", builds[0][1], lines, {"CUDECOMP_WORKSPACE_POOL_MIB": "0"})
+libs = os.path.join(ROOT, "scripts", "probe", "ab_libs")
+T = {"CUDECOMP_DEBUG_DESTROY_TIMING": "1", "CUDECOMP_TEST_PHASE_TIMES": "1"}
+big = {"LD_LIBRARY_PATH": os.path.join(libs, "head_big")}
+run("HEAD (small device code)", builds[1][1], lines, T)
+run("HEAD with the big device code, epoch read through pinned memory", builds[1][1], lines, dict(T, **big))
+run("HEAD with the big device code, pageable epoch read", builds[1][1], lines, dict(T, CUDECOMP_DEBUG_PAGEABLE_EPOCH_READ="1", **big))

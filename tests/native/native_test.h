@@ -140,6 +140,24 @@ inline int localRank() {
 }
 #endif
 
+// where the time of a case goes (CUDECOMP_TEST_PHASE_TIMES=1 prints the sums of rank 0 at the end)
+struct PhaseTimes {
+  static constexpr int N = 8;
+  double sum[N] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const char* name[N] = {"create", "alloc", "fill+h2d", "transposes", "sync", "d2h+compare", "free", "destroy"};
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void start() { t = std::chrono::steady_clock::now(); }
+  void mark(int i) {
+    const auto now = std::chrono::steady_clock::now();
+    sum[i] += std::chrono::duration<double>(now - t).count();
+    t = now;
+  }
+};
+inline PhaseTimes& phaseTimes() {
+  static PhaseTimes p;
+  return p;
+}
+
 // path counters of the library, summed over the cases of this process (printed at the end by the MPI build)
 inline int64_t& mpiPathTransposes() {
   static int64_t n = 0;
@@ -466,6 +484,11 @@ int nativeMain(int argc, char** argv, RunCase run_case) {
     MPI_Finalize();
   }
 #endif
+  if (rank == 0 && std::getenv("CUDECOMP_TEST_PHASE_TIMES")) {
+    printf("Phase times [s]:");
+    for (int i = 0; i < PhaseTimes::N; ++i) printf(" %s %.3f", phaseTimes().name[i], phaseTimes().sum[i]);
+    printf("\n");
+  }
   if (rank == 0 && queueCensus()[0] >= 0)  // (ranks sharing a GPU: more compute queues than slots = the driver time-slices them)
     printf("Device queues: at most %lld compute queues of all processes on this GPU, %lld hardware queue slots\n",
            (long long)queueCensus()[0], (long long)queueCensus()[1]);

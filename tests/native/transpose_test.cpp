@@ -51,7 +51,9 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
   else options.autotune_transpose_backend = true;
 
   cudecompGridDesc_t gdesc;
+  phaseTimes().start();
   T_CHECK_CD(cudecompGridDescCreate(handle, &gdesc, &config, &options));
+  phaseTimes().mark(0);
   if (!silent && rank == 0)
     printf("running on %d x %d x %d spatial grid, %d x %d process grid, %s transpose backend...\n", g[0], g[1], g[2],
            config.pdims[0], config.pdims[1], cudecompTransposeCommBackendToString(config.transpose_comm_backend));
@@ -72,11 +74,13 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
       if (oop) data2 = TestBuffer::get(1, nel);
     }
     T_CHECK_CD(cudecompMalloc(handle, gdesc, (void**)&work, std::max<int64_t>(ws, 1) * sizeof(elem_t)));
+    phaseTimes().mark(1);
 
     const std::array<bool, 3> none = {false, false, false};
     std::vector<elem_t> ref[3], host(nel);
     for (int ax = 0; ax < 3; ++ax) fillPencil(ref[ax], p[ax], g, false, none);
     T_CHECK_HIP(hipMemcpy(data, ref[0].data(), p[0].size * sizeof(elem_t), hipMemcpyHostToDevice));
+    phaseTimes().mark(2);
 
     struct Hop {
       const char* name;
@@ -93,7 +97,9 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
       if (sentinel) T_CHECK_HIP(hipMemset(out, 0xEE, p[h.to].size * sizeof(elem_t)));
       T_CHECK_CD(h.fn(handle, gdesc, in, out, work, kDtype, halo[h.from].data(), halo[h.to].data(), pad[h.from].data(),
                       pad[h.to].data(), 0));
+      phaseTimes().mark(3);
       T_CHECK_HIP(hipDeviceSynchronize());
+      phaseTimes().mark(4);
       if (hop_index == 0 && rank == worldSize() - 1 && std::getenv("CUDECOMP_TEST_INJECT_FAULT"))  // exercises the DIAG path
         T_CHECK_HIP(hipMemset(out + p[h.to].size / 2, 0xEE, std::min<int64_t>(1000, p[h.to].size / 2) * sizeof(elem_t)));
       host.resize(p[h.to].size);
@@ -107,6 +113,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
         diagnoseMismatch(h.name, out, host, ref[h.to], previous, p[h.to], true);
       }
       ++hop_index;
+      phaseTimes().mark(5);
       if (oop) std::swap(in, out);
     }
   } catch (...) {
@@ -130,7 +137,9 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
   }
   T_CHECK_CD(cudecompFree(handle, gdesc, work));
   notePaths(handle, gdesc);
+  phaseTimes().mark(6);
   T_CHECK_CD(cudecompGridDescDestroy(handle, gdesc));
+  phaseTimes().mark(7);
   return failures ? 1 : 0;
 }
 

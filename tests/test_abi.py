@@ -314,3 +314,17 @@ def test_autotune_prior_follows_the_plans(handle, monkeypatch):
     # 1 x 1: four local permutations, no exchange; in place costs the staging pass
     assert est((1, 1), b) < est((1, 1), b, inplace=True)
     assert est((1, 1), b, orders=default, inplace=True) == 0.0  # identical layouts in place: nothing to do
+
+
+def test_device_code_stays_small():
+    """A measured platform limit, not a style rule (profiles/r04_tuning.md, "device code size"): when the library's device
+    code (.hip_fatbin) grew from 0.59 MB to 0.72 MB -- twenty more instantiations of the transpose kernel -- every small
+    synchronous operation on the null stream of a process that had copied through IPC mappings took 14 ms (descriptor
+    destruction: 27 ms; the 4- and 8-rank test sweeps ran five times longer); at 0.61 MB it does not.  Kernel variants that
+    only tuning switches select live behind `make TUNING_VARIANTS=1`."""
+    import subprocess
+    lib = os.path.join(ROOT, "cudecomp_amd", "lib", "libcudecomp.so")
+    out = subprocess.run(["readelf", "-S", "-W", lib], capture_output=True, text=True).stdout
+    sizes = [int(l.split()[5], 16) for l in out.splitlines() if ".hip_fatbin " in l]
+    assert sizes, "no .hip_fatbin section found"
+    assert sizes[0] < 600_000, "device code grew to %d bytes: see the docstring before adding kernel instantiations" % sizes[0]

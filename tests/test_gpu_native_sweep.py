@@ -144,12 +144,11 @@ def test_sweep_eight_ranks():
                                  {"CUDECOMP_DISABLE_DIRECT_PUT": "1", "CUDECOMP_PEER_COPY_ENGINE": "sdma"},
                                  {"CUDECOMP_PEER_COPY_ENGINE": "cu"}, {"CUDECOMP_INTERLEAVE_ROWS": "0"},
                                  {"CUDECOMP_PIPELINE_STAGES": "1"}, {"CUDECOMP_PIPELINE_STAGES": "7", "CUDECOMP_PEER_COPY_ENGINE": "sdma"},
-                                 {"CUDECOMP_WORKSPACE_POOL_MIB": "0"},
-                                 {"CUDECOMP_WINDOW_STORES": "1", "CUDECOMP_WINDOW_WIDE": "1"}],
+                                 {"CUDECOMP_WORKSPACE_POOL_MIB": "0"}],
                          ids=["graphs", "performance_report", "cached_access_i_first", "generic_kernels", "plain_halo_sequence",
                               "overlapped_halo_any_size", "window_stores_any_size", "copy_engines_staged_put", "kernel_copies",
                               "row_copies_one_move_after_the_other", "one_pipeline_stage", "seven_pipeline_stages_copy_engines",
-                              "no_workspace_pool", "wide_window_tiles"])
+                              "no_workspace_pool"])
 def test_sweep_library_switches_do_not_change_results(env):
     """Environment switches of the library (graph capture of the pipelined pack loop, the performance report, kernel
     tuning / debug switches) on a slice of the base sweep: results stay exact."""
