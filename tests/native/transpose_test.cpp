@@ -111,6 +111,14 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
         // what `out` held before this hop (out of place, no sentinel): the pencil written two hops earlier
         const std::vector<elem_t>* previous = (oop && !sentinel && hop_index >= 1) ? &ref[hops[hop_index - 1].from] : nullptr;
         diagnoseMismatch(h.name, out, host, ref[h.to], previous, p[h.to], true);
+        // Is the INPUT pencil intact now?  (Out of place only: it is still there.)  Hypothesis to check with the next
+        // failure: the synchronous upload of the test program had not fully landed when the hop read it.
+        if (oop) {
+          std::vector<elem_t> again(p[h.from].size);
+          T_CHECK_HIP(hipMemcpy(again.data(), in, p[h.from].size * sizeof(elem_t), hipMemcpyDeviceToHost));
+          const int64_t in_bad = countMismatches(again, ref[h.from], p[h.from], true);
+          fprintf(stderr, "DIAG rank %d %s: input pencil now: %lld wrong interior cells\n", rank, h.name, (long long)in_bad);
+        }
       }
       ++hop_index;
       phaseTimes().mark(5);
