@@ -488,6 +488,10 @@ class PeerContext {
       CD_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ci.dev_epoch), 256));
       const u64 base = ci.epoch_base;
       CD_CHECK_HIP(hipMemcpy(ci.dev_epoch, &base, sizeof(base), hipMemcpyHostToDevice));
+      // the counter is first touched by a kernel on the CALLER's stream, which need not be ordered behind a synchronous
+      // copy from pageable memory (it may return once the bytes are staged): make sure they are in place -- once per
+      // communicator
+      CD_CHECK_HIP(hipDeviceSynchronize());
     }
     return ci.dev_epoch;
   }
