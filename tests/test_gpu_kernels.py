@@ -20,8 +20,9 @@ def run_move(es, extent, ss, ds, src_len, dst_len, src_off=0, dst_off=0, seed=0,
     exp = dst0.copy()
     orc.move3d_reference(src, exp, extent, ss, ds, src_off, dst_off)
     # fast path, generic fallback, fast path with streaming access, window variant of the transposes (with and without
-    # streaming) for every destination off the 64-byte grid; 4-byte elements: the 128 x 64 and 64 x 128 tile variants;
-    # the diagnostic store policy / tile walk of the shared-GPU hunt
+    # streaming) for every destination off the 64-byte grid; 4-byte elements: the tile-shape switches (they select other
+    # tiles only in `make TUNING_VARIANTS=1` builds, the default build always uses 64 x 128); the diagnostic store policy /
+    # tile walk of the shared-GPU hunt
     for force_generic in (0, 1, 2, 4, 6) + ((16, 32, 18, 34) if es == 4 else ()) + (64, 128 + 2):
         d_src, d_dst = G.to_device(src.view(np.uint8)), G.to_device(dst0.view(np.uint8))
         cls = cd.cudecompExtMove3D(d_src.data_ptr() + src_off * es, d_dst.data_ptr() + dst_off * es, es, extent, ss, ds,
