@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcudecomp.so")
+# (CUDECOMP_AMD_LIBRARY: another build of the same library, e.g. cudecomp_amd/lib_asan/libcudecomp.so for sanitizer runs)
+LIB_PATH = os.environ.get("CUDECOMP_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libcudecomp.so")
 
 # ---- enums (cudecomp.h) ---------------------------------------------------------------------------
 TRANSPOSE_COMM_MPI_P2P, TRANSPOSE_COMM_MPI_P2P_PL, TRANSPOSE_COMM_MPI_A2A = 1, 2, 3

@@ -70,15 +70,24 @@ void checkDataType(cudecompDataType_t t) {
     default: CD_INVALID_USAGE("unknown data type");
   }
 }
-void checkTransposeBackend(cudecompTransposeCommBackend_t b) {
+// Enum fields of caller-filled structs are read as the 32-bit integers they are in memory: a value outside the enum's range
+// (exactly what these checks are for) must not be loaded through the enum type first (undefined behaviour; UBSan flags it).
+template <typename E>
+int32_t rawEnum(const E& field) {
+  static_assert(sizeof(E) == sizeof(int32_t), "enum fields of the public structs are 32-bit");
+  int32_t v;
+  std::memcpy(&v, &field, sizeof(v));
+  return v;
+}
+void checkTransposeBackend(int32_t b) {
   if (b < CUDECOMP_TRANSPOSE_COMM_MPI_P2P || b > CUDECOMP_TRANSPOSE_COMM_NVSHMEM_SM)
     CD_INVALID_USAGE("unknown transpose communication type");
 }
-void checkHaloBackend(cudecompHaloCommBackend_t b) {
+void checkHaloBackend(int32_t b) {
   if (b < CUDECOMP_HALO_COMM_MPI || b > CUDECOMP_HALO_COMM_NVSHMEM_BLOCKING)
     CD_INVALID_USAGE("unknown halo communication type");
 }
-void checkRankOrder(cudecompRankOrder_t r) {
+void checkRankOrder(int32_t r) {
   if (r != CUDECOMP_RANK_ORDER_DEFAULT && r != CUDECOMP_RANK_ORDER_ROW_MAJOR && r != CUDECOMP_RANK_ORDER_COL_MAJOR)
     CD_INVALID_USAGE("unknown rank order");
 }
@@ -150,9 +159,9 @@ void copyConfigOut(cudecompGridDescConfig_t* dst, int64_t struct_size, int32_t v
 }
 
 void validateConfig(cudecompHandle_t h, const cudecompGridDescConfig_t& c, bool autotune_transpose, bool autotune_halo) {
-  if (!autotune_transpose) checkTransposeBackend(c.transpose_comm_backend);
-  if (!autotune_halo) checkHaloBackend(c.halo_comm_backend);
-  checkRankOrder(c.rank_order);
+  if (!autotune_transpose) checkTransposeBackend(rawEnum(c.transpose_comm_backend));
+  if (!autotune_halo) checkHaloBackend(rawEnum(c.halo_comm_backend));
+  checkRankOrder(rawEnum(c.rank_order));
   if (c.pdims[0] < 0 || c.pdims[1] < 0) CD_INVALID_USAGE("pdims values are invalid");
   const int64_t prod = (int64_t)c.pdims[0] * c.pdims[1];
   if (prod == 0) {
@@ -598,10 +607,11 @@ cudecompResult_t cudecompGridDescCreateVersioned(cudecompHandle_t handle, cudeco
     prepareTransports(handle, need_rccl, need_peer);
 
     if (have_opt) {
-      if (opt.grid_mode == CUDECOMP_AUTOTUNE_GRID_TRANSPOSE) {
+      const int32_t grid_mode = rawEnum(opt.grid_mode);  // (validated here: never loaded through the enum type first)
+      if (grid_mode == CUDECOMP_AUTOTUNE_GRID_TRANSPOSE) {
         if (tune_tb || tune_pdims) autotuneTranspose(handle, gd, &opt, tune_tb, tune_pdims);
         if (tune_hb) autotuneHalo(handle, gd, &opt, tune_hb, false);
-      } else if (opt.grid_mode == CUDECOMP_AUTOTUNE_GRID_HALO) {
+      } else if (grid_mode == CUDECOMP_AUTOTUNE_GRID_HALO) {
         if (tune_hb || tune_pdims) autotuneHalo(handle, gd, &opt, tune_hb, tune_pdims);
         if (tune_tb) autotuneTranspose(handle, gd, &opt, tune_tb, false);
       } else {
