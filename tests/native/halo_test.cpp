@@ -67,7 +67,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     std::vector<elem_t> init, ref, host(p.size);
     fillPencil(init, p, g, false, periods);
     fillPencil(ref, p, g, true, periods);
-    T_CHECK_HIP(hipMemcpy(data, init.data(), p.size * sizeof(elem_t), hipMemcpyHostToDevice));
+    uploadPencil(data, init.data(), p.size * sizeof(elem_t));
     bool pb[3] = {periods[0], periods[1], periods[2]};
     for (int dim = 0; dim < 3; ++dim) {
       if (axis == 0) T_CHECK_CD(cudecompUpdateHalosX(handle, gdesc, data, work, kDtype, halo.data(), pb, dim, pad.data(), 0));

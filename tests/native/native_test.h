@@ -384,6 +384,32 @@ inline void diagnoseMismatch(const char* what, const elem_t* dev, const std::vec
           seen_mask[7], (long long)bad2);
 }
 
+// How the test programs upload a pencil.  Default: the synchronous hipMemcpy from pageable memory the reference's programs use.
+// CUDECOMP_TEST_UPLOAD=sync adds a hipDeviceSynchronize behind it; =pinned goes through a pinned staging buffer with
+// hipMemcpyAsync + hipStreamSynchronize on the null stream.  Arms of the hunt (did a consumer kernel ever
+// run before the pageable upload had landed?).
+inline void uploadPencil(void* dst, const void* src, size_t bytes) {
+  static const int mode = [] {
+    const char* v = std::getenv("CUDECOMP_TEST_UPLOAD");
+    return !v ? 0 : (!std::strcmp(v, "sync") ? 1 : (!std::strcmp(v, "pinned") ? 2 : 0));
+  }();
+  if (mode == 2) {
+    static void* pinned = nullptr;
+    static size_t cap = 0;
+    if (cap < bytes) {
+      if (pinned) T_CHECK_HIP(hipHostFree(pinned));
+      cap = std::max<size_t>(bytes, (size_t)16 << 20);
+      T_CHECK_HIP(hipHostMalloc(&pinned, cap, hipHostMallocDefault));
+    }
+    std::memcpy(pinned, src, bytes);
+    T_CHECK_HIP(hipMemcpyAsync(dst, pinned, bytes, hipMemcpyHostToDevice, nullptr));
+    T_CHECK_HIP(hipStreamSynchronize(nullptr));
+    return;
+  }
+  T_CHECK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  if (mode == 1) T_CHECK_HIP(hipDeviceSynchronize());
+}
+
 // Data buffers of the test programs: hipMalloc / hipFree per case as the reference's programs do, or -- with
 // CUDECOMP_TEST_REUSE_BUFFERS=1 (an arm of the hunt: does allocation churn matter?) -- grown once and kept for the process.
 struct TestBuffer {

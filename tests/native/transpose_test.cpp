@@ -79,7 +79,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     const std::array<bool, 3> none = {false, false, false};
     std::vector<elem_t> ref[3], host(nel);
     for (int ax = 0; ax < 3; ++ax) fillPencil(ref[ax], p[ax], g, false, none);
-    T_CHECK_HIP(hipMemcpy(data, ref[0].data(), p[0].size * sizeof(elem_t), hipMemcpyHostToDevice));
+    uploadPencil(data, ref[0].data(), p[0].size * sizeof(elem_t));
     phaseTimes().mark(2);
 
     struct Hop {
