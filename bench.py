@@ -535,7 +535,7 @@ def main():
         # (no GPU_MAX_HW_QUEUES setting for a GPU per rank any more: the one-sided transport never parks a wait kernel on a
         # copy stream and, with kernel copies, uses ONE copy stream beside the caller's, so the runtime's default of 4
         # hardware queues per process is enough.)  Ranks that SHARE a device -- flow checks on a one-GPU box, never a
-        # measurement -- must not exceed its hardware queue slots (DESIGN.md section 9 B): two queues per process then.
+        # measurement -- must not exceed its hardware queue slots (DESIGN.md section 9): two queues per process then.
         if gpus_on_this_host() * 5 < world:
             os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     import torch

@@ -88,10 +88,12 @@ def kfd_queue_census():
 
 
 def shared_device_env(nranks, env):
-    """Hook for ranks that SHARE a GPU.  Measured in round 3 (DESIGN.md section 9 B): eight processes with the runtime's
+    """Hook for ranks that SHARE a GPU.  Measured in round 3 (DESIGN.md section 9): eight processes with the runtime's
     default of four hardware queues each can push the device into time-slicing its queues (4-5x slower, rarely a wrong
     result in a kernel of ANY kind); GPU_MAX_HW_QUEUES=2 made the 8-rank stress and the complete 8-rank reference matrix
-    clean -- but one full-suite run with it hung in an 8-rank sweep, so it is NOT applied by default.  The library keeps
+    clean -- but one full-suite run with it hung in an 8-rank sweep, so it is NOT applied by default.  (Round 4: the census
+    shows that the value 2 does not lower the processes' queue count at all -- 26 compute queues with and without it -- while
+    1 does; the regime is entered above the device's 24 compute-queue slots, profiles/r04_tuning.md.)  The library keeps
     its own stream count at two per process on shared devices instead; set CUDECOMP_TEST_SHARED_GPU_QUEUES=N to try a
     queue limit for runs with more than five ranks per device."""
     want = os.environ.get("CUDECOMP_TEST_SHARED_GPU_QUEUES")
