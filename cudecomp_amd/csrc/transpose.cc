@@ -305,7 +305,8 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
     perfMark(pev, 3, stream);
     return;
   }
-  if (!pipelined && xpath == PATH_PEER_BARRIER && transposeBackendIsPeer(backend) && !h->self_exchange &&
+  const bool engines_asked_for = h->peer_copy_engine_pinned && h->peer_copy_engine == 0;  // CUDECOMP_PEER_COPY_ENGINE=sdma
+  if (!pipelined && xpath == PATH_PEER_BARRIER && transposeBackendIsPeer(backend) && !h->self_exchange && !engines_asked_for &&
       plan.pencil_elements_a * es <= h->fuse_small_bytes) {
     // Small exchanges of the NVSHMEM enum are latency-bound: eight launches and two cross-stream hand-offs (pack, ready wait,
     // copy kernel on the copy stream, signal, self copy, landed wait, unpack) against six launches on ONE stream when the
