@@ -68,6 +68,10 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     fillPencil(init, p, g, false, periods);
     fillPencil(ref, p, g, true, periods);
     uploadPencil(data, init.data(), p.size * sizeof(elem_t));
+    // input-integrity gate (native_test.h): what a kernel on the library's stream sees of the upload, BEFORE the updates
+    if (rank == worldSize() - 1 && std::getenv("CUDECOMP_TEST_INJECT_STALE_INPUT"))  // self-check of the gate
+      T_CHECK_HIP(hipMemset(data + p.size / 2, 0xEE, std::min<int64_t>(100, p.size / 2) * sizeof(elem_t)));
+    const bool stale_input = InputGate::get().checkInput("halo", data, init, p.size, 0);
     bool pb[3] = {periods[0], periods[1], periods[2]};
     for (int dim = 0; dim < 3; ++dim) {
       if (axis == 0) T_CHECK_CD(cudecompUpdateHalosX(handle, gdesc, data, work, kDtype, halo.data(), pb, dim, pad.data(), 0));
@@ -76,9 +80,18 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     }
     T_CHECK_HIP(hipDeviceSynchronize());
     T_CHECK_HIP(hipMemcpy(host.data(), data, p.size * sizeof(elem_t), hipMemcpyDeviceToHost));
+    InputGate::get().checkDownload("halo", data, host, p.size, 0);
+    // a halo update never writes interior cells: they must still hold what was uploaded
+    const int64_t interior_bad = countMismatches(host, init, p, true);
+    if (interior_bad) {
+      ++InputGate::get().interior_overwritten;
+      fprintf(stderr, "DIAG rank %d halo: interior overwritten after call: %lld interior cells differ from the upload\n", rank,
+              (long long)interior_bad);
+    }
     const int64_t bad = countMismatches(host, ref, p, false);
     if (bad) {
-      fprintf(stderr, "rank %d: %lld cells differ after the halo updates\n", rank, (long long)bad);
+      fprintf(stderr, "rank %d: %lld cells differ after the halo updates%s\n", rank, (long long)bad,
+              stale_input ? " (the input gate had TRIPPED for this case: stale upload)" : " (input gate: the upload was intact before the call)");
       ++failures;
       diagnoseMismatch("halo", data, host, ref, &init, p, false);
     }

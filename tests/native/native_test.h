@@ -410,6 +410,100 @@ inline void uploadPencil(void* dst, const void* src, size_t bytes) {
   if (mode == 1) T_CHECK_HIP(hipDeviceSynchronize());
 }
 
+// ---- input-integrity gate (round 5) ------------------------------------------------------------------
+// Decides the "upload hypothesis" behind the rare wrong results of ranks sharing a GPU: did a consumer kernel ever see a
+// pencil whose (synchronous, pageable) upload had not landed?  Right after uploadPencil a checksum KERNEL reads the whole
+// pencil on the stream the library call will use and the sum is compared with the host's sum of what was uploaded, BEFORE the
+// call: a difference prints "DIAG ... input stale before call".  After the call the same kernel sums the result on that
+// stream and the sum is compared with the host copy the verdict is computed from ("download differs from the device's view").
+// On by default (one 1-wave-per-CU kernel and an 8-byte copy per check); CUDECOMP_TEST_INPUT_GATE=0 switches it off.
+// The sum is position-weighted (a stale contiguous part cannot cancel) and order-independent (mod 2^64).
+__global__ void gate_sum_k(const unsigned int* __restrict__ w, long long nwords, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long long)gridDim.x * blockDim.x)
+    acc += (unsigned long long)(w[i] ^ (unsigned int)((unsigned long long)i * 2654435761ull)) * (unsigned long long)(2 * i + 1);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+struct InputGate {
+  long long checks = 0, stale_inputs = 0, stale_downloads = 0, interior_overwritten = 0;
+  unsigned long long* d_sum = nullptr;
+  unsigned long long* h_sum = nullptr;
+  static InputGate& get() {
+    static InputGate g;
+    return g;
+  }
+  static bool enabled() {
+    static const bool on = [] { const char* v = std::getenv("CUDECOMP_TEST_INPUT_GATE"); return !v || std::atoi(v) != 0; }();
+    return on;
+  }
+  static unsigned long long hostSum(const void* p, size_t bytes) {
+    const unsigned int* w = static_cast<const unsigned int*>(p);
+    const long long n = (long long)(bytes / 4);
+    unsigned long long acc = 0;
+    for (long long i = 0; i < n; ++i)
+      acc += (unsigned long long)(w[i] ^ (unsigned int)((unsigned long long)i * 2654435761ull)) * (unsigned long long)(2 * i + 1);
+    return acc;
+  }
+  unsigned long long deviceSum(const void* dev, size_t bytes, hipStream_t stream) {
+    if (!d_sum) {
+      T_CHECK_HIP(hipMalloc((void**)&d_sum, 8));
+      T_CHECK_HIP(hipHostMalloc((void**)&h_sum, 8, hipHostMallocDefault));
+    }
+    T_CHECK_HIP(hipMemsetAsync(d_sum, 0, 8, stream));
+    gate_sum_k<<<256, 256, 0, stream>>>(static_cast<const unsigned int*>(dev), (long long)(bytes / 4), d_sum);
+    T_CHECK_HIP(hipGetLastError());
+    T_CHECK_HIP(hipMemcpyAsync(h_sum, d_sum, 8, hipMemcpyDeviceToHost, stream));
+    T_CHECK_HIP(hipStreamSynchronize(stream));
+    return *h_sum;
+  }
+  // BEFORE the call: does a kernel on `stream` see what the host uploaded?  Returns true when the input was stale.
+  bool checkInput(const char* what, const elem_t* dev, const std::vector<elem_t>& uploaded, int64_t nel, hipStream_t stream) {
+    if (!enabled()) return false;
+    ++checks;
+    const size_t bytes = (size_t)nel * sizeof(elem_t);
+    const unsigned long long want = hostSum(uploaded.data(), bytes), got = deviceSum(dev, bytes, stream);
+    if (got == want) return false;
+    ++stale_inputs;
+    // how stale, and is it merely late?  a second kernel look after a device-wide sync, then the cells themselves
+    T_CHECK_HIP(hipDeviceSynchronize());
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    const unsigned long long again = deviceSum(dev, bytes, stream);
+    std::vector<elem_t> back((size_t)nel);
+    T_CHECK_HIP(hipMemcpy(back.data(), dev, bytes, hipMemcpyDeviceToHost));
+    int64_t bad = 0, lo = -1, hi = -1;
+    for (int64_t i = 0; i < nel; ++i)
+      if (!sameBits(back[i], uploaded[i])) {
+        ++bad;
+        if (lo < 0) lo = i;
+        hi = i;
+      }
+    fprintf(stderr,
+            "DIAG rank %d %s: input stale before call: kernel checksum %016llx, host %016llx; second kernel look after a device sync "
+            "%s; read back with hipMemcpy: %lld of %lld cells differ from the upload, in [%lld, %lld] (dev %p)\n",
+            worldRank(), what, got, want, again == want ? "RIGHT (the upload landed late)" : "still wrong", (long long)bad,
+            (long long)nel, (long long)lo, (long long)hi, (const void*)dev);
+    return true;
+  }
+  // AFTER the call (device idle): does the host copy the verdict is computed from agree with what a kernel sees?
+  void checkDownload(const char* what, const elem_t* dev, const std::vector<elem_t>& host, int64_t nel, hipStream_t stream) {
+    if (!enabled()) return;
+    const size_t bytes = (size_t)nel * sizeof(elem_t);
+    const unsigned long long want = hostSum(host.data(), bytes), got = deviceSum(dev, bytes, stream);
+    if (got == want) return;
+    ++stale_downloads;
+    fprintf(stderr, "DIAG rank %d %s: download differs from the device's view: kernel checksum %016llx, host copy %016llx (dev %p)\n",
+            worldRank(), what, got, want, (const void*)dev);
+  }
+  void report() const {
+    if (!enabled()) return;
+    if (worldRank() == 0 || stale_inputs || stale_downloads || interior_overwritten)
+      fprintf(stderr, "Input gate rank %d: %lld uploads checked, %lld stale before the call, %lld downloads differing, %lld halo updates that overwrote interior cells\n",
+              worldRank(), checks, stale_inputs, stale_downloads, interior_overwritten);
+  }
+};
+
 // Data buffers of the test programs: hipMalloc / hipFree per case as the reference's programs do, or -- with
 // CUDECOMP_TEST_REUSE_BUFFERS=1 (an arm of the hunt: does allocation churn matter?) -- grown once and kept for the process.
 struct TestBuffer {
@@ -501,6 +595,7 @@ int nativeMain(int argc, char** argv, RunCase run_case) {
       fflush(stdout);
     }
   }
+  InputGate::get().report();
   (void)cudecompFinalize(handle);
 #ifdef NATIVE_WITH_MPI
   {

@@ -15,7 +15,9 @@
 //   -f|--testfile FILE       one case per line
 // Environment (diagnostics of the shared-GPU hunt, see native_test.h): CUDECOMP_TEST_SENTINEL=1 pre-fills every out-of-place
 // output with 0xEE bytes; CUDECOMP_TEST_REUSE_BUFFERS=1 keeps the data buffers for the whole process; a failing hop always
-// prints two DIAG lines (what the wrong cells hold, who can see the right ones).
+// prints two DIAG lines (what the wrong cells hold, who can see the right ones).  The input-integrity gate (native_test.h,
+// on by default) checks the uploaded pencil with a kernel on the library's stream before the first hop and every download
+// against the device's view after it.
 #include "native_test.h"
 
 static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
@@ -80,6 +82,10 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     std::vector<elem_t> ref[3], host(nel);
     for (int ax = 0; ax < 3; ++ax) fillPencil(ref[ax], p[ax], g, false, none);
     uploadPencil(data, ref[0].data(), p[0].size * sizeof(elem_t));
+    // input-integrity gate (native_test.h): what a kernel on the library's stream sees of the upload, BEFORE the first hop
+    if (rank == worldSize() - 1 && std::getenv("CUDECOMP_TEST_INJECT_STALE_INPUT"))  // self-check of the gate
+      T_CHECK_HIP(hipMemset(data + p[0].size / 2, 0xEE, std::min<int64_t>(100, p[0].size / 2) * sizeof(elem_t)));
+    const bool stale_input = InputGate::get().checkInput("XToY", data, ref[0], p[0].size, 0);
     phaseTimes().mark(2);
 
     struct Hop {
@@ -104,9 +110,11 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
         T_CHECK_HIP(hipMemset(out + p[h.to].size / 2, 0xEE, std::min<int64_t>(1000, p[h.to].size / 2) * sizeof(elem_t)));
       host.resize(p[h.to].size);
       T_CHECK_HIP(hipMemcpy(host.data(), out, p[h.to].size * sizeof(elem_t), hipMemcpyDeviceToHost));
+      InputGate::get().checkDownload(h.name, out, host, p[h.to].size, 0);
       const int64_t bad = countMismatches(host, ref[h.to], p[h.to], true);
       if (bad) {
-        fprintf(stderr, "rank %d: %s: %lld interior cells differ\n", rank, h.name, (long long)bad);
+        fprintf(stderr, "rank %d: %s: %lld interior cells differ%s\n", rank, h.name, (long long)bad,
+                stale_input ? " (the input gate had TRIPPED for this case: stale upload)" : " (input gate: the upload was intact before the call)");
         ++failures;
         // what `out` held before this hop (out of place, no sentinel): the pencil written two hops earlier
         const std::vector<elem_t>* previous = (oop && !sentinel && hop_index >= 1) ? &ref[hops[hop_index - 1].from] : nullptr;
