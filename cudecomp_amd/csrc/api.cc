@@ -351,6 +351,7 @@ cudecompHandle::~cudecompHandle() {
     }
     relay_buf = nullptr;
   }
+  if (relay_last_call) (void)hipEventDestroy(relay_last_call);
   for (hipStream_t s : streams) (void)hipStreamDestroy(s);
   rccl.reset();
   peer.reset();
@@ -447,16 +448,24 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->slot_used.assign(256, false);
     h->slot_high.assign(256, 0);
     h->tuning.no_streaming = envIsOne("CUDECOMP_DISABLE_STREAMING_ACCESS");
-    if (const char* v = std::getenv("CUDECOMP_INTERLEAVE_ROWS")) h->tuning.interleave_rows = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
-    if (const char* v = std::getenv("CUDECOMP_WINDOW_STORES")) h->tuning.window_mode = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
-    if (const char* v = std::getenv("CUDECOMP_WINDOW_WIDE")) h->tuning.window_wide = (int)std::strtol(v, nullptr, 10);  // tuning aid / tests
-    if (const char* v = std::getenv("CUDECOMP_TILE_WALK")) h->tuning.walk_order = (int)std::strtol(v, nullptr, 10);  // tuning aid
-    if (const char* v = std::getenv("CUDECOMP_TILE_SHAPE")) h->tuning.tile_shape = (int)std::strtol(v, nullptr, 10);  // tuning aid
-    if (const char* v = std::getenv("CUDECOMP_XCD_WALK")) h->tuning.xcd_walk = (int)std::strtol(v, nullptr, 10);  // diagnostic
-    if (const char* v = std::getenv("CUDECOMP_LOCAL_STORE_POLICY")) {  // diagnostic: cached | stream | writethrough
-      const std::string e(v);
-      h->tuning.local_store_policy = e == "cached" ? 0 : (e == "stream" ? 1 : (e == "writethrough" ? 2 : -1));
-    }
+    // Tuning switches (kernel variants, walk orders, diagnostic store policies): read by `make TUNING_VARIANTS=1` builds only
+    // (cudecomp_amd/lib_tuning); the default build has neither the variants nor the switches and says so once.
+    auto tuningSwitch = [&](const char* var, int* out) {
+      const char* v = std::getenv(var);
+      if (!v || !*v) return;
+#ifdef CUDECOMP_TUNING_VARIANTS
+      *out = (int)std::strtol(v, nullptr, 10);
+#else
+      (void)out;
+      if (h->rank == 0)
+        printf("CUDECOMP:WARN: %s is a tuning switch of `make TUNING_VARIANTS=1` builds of this library; ignored.\n", var);
+#endif
+    };
+    tuningSwitch("CUDECOMP_INTERLEAVE_ROWS", &h->tuning.interleave_rows);
+    tuningSwitch("CUDECOMP_WINDOW_STORES", &h->tuning.window_mode);
+    tuningSwitch("CUDECOMP_WINDOW_WIDE", &h->tuning.window_wide);
+    tuningSwitch("CUDECOMP_TILE_WALK", &h->tuning.walk_order);
+    tuningSwitch("CUDECOMP_TILE_SHAPE", &h->tuning.tile_shape);
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))
       if (std::strtol(v, nullptr, 10) == 1) h->tuning.force_class = MOVE_GENERIC;
 
@@ -485,9 +494,9 @@ cudecompResult_t cudecompFinalize(cudecompHandle_t handle) {
       } catch (const Error& e) {
         pending = std::make_unique<Error>(e);
       }
-      // ranks sharing a device: one more look at the device's hardware queues (the first was when the transport came up;
-      // not per call -- reading the driver's tables contends with the other ranks' queue management)
-      if (handle->nranks > 1 && !handle->link_crosses_devices) (void)peerQueueCensus(handle, true);
+      // opt-in (CUDECOMP_QUEUE_CENSUS=1): one more look at the device's hardware queues (the first was when the transport
+      // came up; never per call)
+      if (handle->nranks > 1 && peerQueueCensusRequested()) (void)peerQueueCensus(handle, true);
     }
     delete handle;
     if (pending) throw *pending;

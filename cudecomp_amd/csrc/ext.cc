@@ -474,7 +474,9 @@ cudecompResult_t cudecompExtRunLocalPhases(const cudecompExtGridSpec_t* grid, in
     const TransposePlan p = buildTransposePlan(g, rank, (TransposeOp)op, zero, zero, zero, zero, input == output, traits, P);
     void* bufs[3] = {input, output, work};
     KernelTuning t;
+#ifdef CUDECOMP_TUNING_VARIANTS
     if (const char* v = std::getenv("CUDECOMP_INTERLEAVE_ROWS")) t.interleave_rows = (int)std::strtol(v, nullptr, 10);
+#endif
     // the launches of the executor: one batched launch per phase; pipelined: one launch per STAGE with all peers in it
     // for the one-sided transport (transport.cc: peerStagedExchange), one launch per PEER for RCCL / MPI (the reference's
     // pipeline, transpose.h:470-513, 683-744)
@@ -530,8 +532,8 @@ cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const
     if (force_generic & 8) t.window_mode = 0;  // never
     if (force_generic & 16) t.tile_shape = 1;  // 4-byte transposes: 128 x 64 tiles
     if (force_generic & 32) t.tile_shape = 0;  // 4-byte transposes: 64 x 64 tiles (the default is 64 x 128)
-    if (force_generic & 64) t.local_store_policy = 2;  // write-through stores (diagnostic policy of section 9)
-    if (force_generic & 128) t.xcd_walk = 0;
+    if (force_generic & 64) t.walk_order = 0;  // transposes: i first
+    if (force_generic & 128) t.walk_order = 1;  // transposes: j first (no runs)
     KernelStats st;
     launchMoves(&m, 1, bufs, es, stream, &t, &st);
     if (kernel_class) {

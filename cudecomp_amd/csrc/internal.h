@@ -76,6 +76,7 @@ struct cudecompHandle {
   bool two_hop_relay = false;         // CUDECOMP_TWO_HOP_RELAY=1: low-fan-out exchanges of the NVSHMEM enum travel through all ranks of the node
   void* relay_buf = nullptr;          // my relay region (a library region mapped into every rank), grown on demand
   size_t relay_bytes = 0;
+  hipEvent_t relay_last_call = nullptr;  // end of the handle's last relayed transpose (relayed calls run one after the other)
   int census_compute_queues = -1, census_queue_slots = 0;  // last census of the device's compute queues (transport.cc)
   bool queue_warned = false;          // the "hardware queues oversubscribed" note (ranks sharing a device) was printed
   bool halo_overlap_disable = false;  // CUDECOMP_DISABLE_HALO_OVERLAP=1

@@ -1,0 +1,341 @@
+// kernels.cc -- host side of the data-movement kernels: how a Move3D (plan.h) is executed on the GPU.
+//
+// A move is normalised (unit dims dropped, contiguous dims fused, dims sorted by source stride), classified -- row copy,
+// LDS-tiled transposition (plain or "window" for destinations off the 64-byte grid), generic element-wise -- and batched with its
+// siblings (up to kMaxBatch moves, e.g. the per-peer pack copies of one transpose, share one launch; the descriptors travel in
+// the kernel argument segment).  The kernels themselves live in kernels_rows.hip, kernels_transpose.hip (one code object per
+// element size) and kernels_window.hip; kernels_dev.h says why they are separate code objects.
+//
+// Pure data movement: no MFMA; the bound is HBM (8 TB/s spec, ~6.3 TB/s achievable copy rate).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "errors.h"
+#include "kernels.h"
+#include "kernels_batch.h"
+
+namespace cudecomp {
+
+using namespace kern;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// classification
+// ---------------------------------------------------------------------------------------------
+struct Classified {
+  MoveClass cls;
+  int variant;  // rows: vector bytes; transpose: elements per vector
+  DevMove dm;
+  int p0, p1;
+  int stream;  // 0 default caching, 1 streaming loads, 2 streaming loads + stores, 3 streaming loads + remote stores
+  bool swizzle = false;  // transposes: XOR-swizzled LDS tile (else padded rows)
+  bool window = false;   // transposes: destination rows off the 64-byte grid -> transpose_window_kernel
+  unsigned int t0, t1;
+  unsigned long long blocks;
+  i64 elements;
+};
+
+int ilog2ceil(long long x) {
+  int l = 0;
+  while ((1LL << l) < x) ++l;
+  return l;
+}
+
+Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelTuning* tuning, void* dst_base,
+                    bool remote) {
+  Move3D m = in;
+  normalizeMove(m);
+  Classified c{};
+  c.elements = m.elements();
+  c.stream = ((c.elements * es >= kStreamBytes || (tuning && tuning->force_streaming)) && !(tuning && tuning->no_streaming)) ? 2 : 0;
+  if (remote) c.stream = 3;  // destination in a peer's memory: write-through stores, whatever the size
+  c.dm.src = static_cast<const char*>(bufs[m.src_buf]) + m.src_off * es;
+  c.dm.dst = static_cast<char*>(dst_base ? dst_base : bufs[m.dst_buf]) + m.dst_off * es;
+  const bool force_generic = tuning && tuning->force_class == MOVE_GENERIC;
+
+  if (!force_generic && m.ss[0] <= 1 && m.ds[0] <= 1) {
+    // rows contiguous on both sides (also the all-extents-1 case).  Widest vector that divides the row length;
+    // addresses only need the element's natural alignment (see GlobalBytes).
+    int vb = 16;
+    while (vb > es && (m.extent[0] * es) % vb != 0) vb >>= 1;
+    c.cls = MOVE_ROWS_VEC;
+    c.variant = vb;
+    c.dm.e[0] = m.extent[0] * es / vb;
+    c.dm.e[1] = m.extent[1];
+    c.dm.e[2] = m.extent[2];
+    for (int i = 1; i < 3; ++i) {
+      c.dm.ss[i] = m.ss[i] * es;
+      c.dm.ds[i] = m.ds[i] * es;
+    }
+    // rows that land off the 64-byte grid (and are long enough for it to matter): lanes laid out from the unit boundary
+    // below each row's start (rows_shifted_kernel), one unit of slack vectors per row
+    const uintptr_t dst_bits = reinterpret_cast<uintptr_t>(c.dm.dst) | (uintptr_t)c.dm.ds[1] | (uintptr_t)c.dm.ds[2];
+    const int shift_mode = tuning ? tuning->window_mode : -1;
+    if ((dst_bits & 63) != 0 && m.extent[0] * es >= 256 && shift_mode != 0 && (shift_mode == 1 || c.elements * es >= (1ll << 20))) {
+      c.window = true;
+      c.p1 = (int)(m.extent[0] * es);  // row length in bytes (rows longer than 2 GiB keep the plain kernel)
+      if (m.extent[0] * es > 0x7fffffffLL) c.window = false;
+    }
+    if (c.window) c.dm.e[0] += 64 / vb;  // one unit of slack vectors per row (see rows_shifted_kernel)
+    c.p0 = std::min(8, ilog2ceil(c.dm.e[0]));
+    const long long lpr = 1LL << c.p0, rows_per_block = (long long)(kThreads >> c.p0) * kRowsUnroll;
+    c.t0 = (unsigned int)((c.dm.e[0] + lpr - 1) / lpr);
+    c.t1 = (unsigned int)((c.dm.e[1] + rows_per_block - 1) / rows_per_block);
+    c.blocks = (unsigned long long)c.t0 * c.t1 * (unsigned long long)c.dm.e[2];
+    return c;
+  }
+
+  int t = -1;
+  if (!force_generic && m.ss[0] == 1) {
+    if (m.ds[1] == 1) t = 1;
+    if (m.ds[2] == 1) t = 2;
+  }
+  if (t > 0 && m.extent[0] >= 4 && m.extent[t] >= 4) {
+    const int k = 3 - t;
+    c.cls = MOVE_TRANSPOSE;
+    c.dm.e[0] = m.extent[0];
+    c.dm.e[1] = m.extent[t];
+    c.dm.e[2] = m.extent[k];
+    c.dm.ss[0] = 1;
+    c.dm.ss[1] = m.ss[t];
+    c.dm.ss[2] = m.ss[k];
+    c.dm.ds[0] = m.ds[0];
+    c.dm.ds[1] = 1;
+    c.dm.ds[2] = m.ds[k];
+    // 16 bytes per lane whenever both tile edges hold whole vectors (no alignment requirement, see GlobalBytes)
+    int vw = 16 / es;
+    if (c.dm.e[0] % vw != 0 || c.dm.e[1] % vw != 0) vw = 1;
+    c.variant = vw;
+    c.p1 = 1;  // XCD-contiguous tile walk
+    c.swizzle = es != 16;
+    // Tile walk order inside an XCD's run: j first makes consecutive tiles extend the same DESTINATION rows
+    // (contiguous write stream per row), i first the same source rows.  Measured on 8 GiB permutations
+    // (profiles/r01_tuning.md): j first wins or ties for line-aligned moves (8-11 % at 16-byte elements and on
+    // the strided-read side at 4-byte elements; 4-byte moves whose destination rows are the far-strided side
+    // lose 1-3 % and keep i first), i first wins by 5-10 % for misaligned moves, where L2 merges the
+    // partially read lines of neighbouring tiles.
+    bool j_first = es != 4 || c.dm.ss[1] > c.dm.ds[0];
+    // Rows that do not start on cache-line boundaries (halo-shifted or odd-extent pencils) leave partially covered
+    // lines at both ends of every tile row.
+    //  * Misaligned SOURCE rows only: the partially used lines are shared with the neighbouring tile; cached loads let
+    //    L2 serve the second use (non-temporal loads fetch them twice), the aligned stores keep streaming.
+    //  * Misaligned DESTINATION rows: partial 64-byte units written by two tiles are what costs (a cached store lets L2
+    //    merge some: fp32 3.0 -> 4.4 TB/s, fp64 3.9 -> 4.8 TB/s on a halo-shifted 8 GiB permutation); the window kernel
+    //    writes whole units instead (4.8 -> 5.1-5.3 TB/s), with streaming stores.
+    const uintptr_t src_bits = reinterpret_cast<uintptr_t>(c.dm.src) | (uintptr_t)(c.dm.ss[1] * es) | (uintptr_t)(c.dm.ss[2] * es);
+    const uintptr_t dst_bits = reinterpret_cast<uintptr_t>(c.dm.dst) | (uintptr_t)(c.dm.ds[0] * es) | (uintptr_t)(c.dm.ds[2] * es);
+    const uintptr_t align_req = 128;
+    const bool src_mis = src_bits % align_req != 0, dst_mis = dst_bits % 64 != 0;
+    const int window_mode = tuning ? tuning->window_mode : -1;  // -1 auto, 0 never, 1 whenever the destination is misaligned
+    c.window = dst_mis && window_mode != 0 && (window_mode == 1 || c.elements * es >= (1ll << 20));
+    if (c.window) {
+      if (c.stream == 2) c.stream = 4;  // cached loads (the overlap rows hit in L2), streaming whole-unit stores
+      j_first = true;
+    } else if (src_mis || dst_bits % align_req != 0) {
+      if (c.stream == 2) {
+        if (dst_bits % align_req != 0) c.stream = 0;
+        else c.stream = 4;
+      }
+      j_first = false;
+    }
+    // One measured outlier: 16-byte elements whose destination batch stride is not a multiple of 4 KiB (rows padded by a
+    // cache line) lose a third of their rate with streaming stores (8 GiB permutation: 4.0 ms streaming, 3.4 ms cached;
+    // 4- and 8-byte elements with the same padding prefer streaming, profiles/r02_tuning.md).
+    if (es == 16 && c.stream == 2 && !c.window && c.dm.e[2] > 1 && ((uintptr_t)(c.dm.ds[2] * es) % 4096) != 0) c.stream = 0;
+    const bool walk_forced = tuning && tuning->walk_order >= 0;
+    if (walk_forced) j_first = tuning->walk_order == 1;
+    // (window kernel, 4-byte elements: 64 x 128 tiles -- a 64-byte unit is 16 elements, the longer window halves the
+    // share of overlap rows)
+    // (window kernel, 8-byte elements, optional: 128 x 64 tiles with 512 threads -- 1-KiB source segments span nine
+    // lines instead of 2 x five; variant 102)
+#ifdef CUDECOMP_TUNING_VARIANTS
+    const bool wide = c.window && es == 8 && vw == 2 && tuning && tuning->window_wide == 1;
+#else
+    const bool wide = false;  // (the 128 x 64 / 512-thread window variant exists in tuning builds only)
+#endif
+    if (wide) c.variant = 102;
+    // (4-byte elements, 16-byte lanes, plain kernel: optional 128 x 64 / 64 x 128 tiles -- variants 204 / 304)
+    int shape = 0;
+    if (!c.window && es == 4 && vw == 4) shape = 2;
+#ifdef CUDECOMP_TUNING_VARIANTS
+    if (!c.window && es == 4 && vw == 4 && tuning && tuning->tile_shape >= 0) shape = tuning->tile_shape;
+#endif
+    if (shape == 1) c.variant = 204;
+    else if (shape == 2) c.variant = 304;
+    // (shape 0 keeps variant 4 = 64 x 64 tiles: only in builds with CUDECOMP_TUNING_VARIANTS)
+    // Large line-aligned moves whose SOURCE rows are the far-strided side (the inverse hops of an axis-contiguous cycle): twice
+    // as many source rows per tile, 1-KiB destination segments.  Measured on the 8-GiB permutations (profiles/r05_tuning.md):
+    // fp64 64 x 128 2.69 -> 2.65 ms, complex128 32 x 64 2.70 -> 2.66 ms; the forward hops lose with these tiles and keep theirs.
+    const bool aligned = !c.window && !src_mis && dst_bits % align_req == 0;
+    const bool far_src = aligned && c.stream == 2 && c.dm.ss[1] > 8 * c.dm.ds[0];
+    bool tall = false;
+    if (far_src && es == 8 && vw == 2 && c.swizzle) {
+      c.variant = 302;
+      tall = true;
+    } else if (far_src && es == 16 && !c.swizzle) {
+      c.variant = 301;
+      tall = true;
+    }
+    const int ti = (es == 16) ? 32 : ((wide || shape == 1) ? 128 : 64);
+    const int tj = (es == 16) ? (tall ? 64 : 32) : (((c.window && es == 4) || shape == 2 || tall) ? 128 : 64);
+    c.t0 = (unsigned int)((c.dm.e[0] + ti - 1) / ti);
+    c.t1 = (unsigned int)((c.dm.e[1] + (c.window ? 64 / es - 1 : 0) + tj - 1) / tj);
+    // Far-strided DESTINATION (the forward hops of an axis-contiguous cycle: destination rows e.g. 8 MiB apart, source rows
+    // near): walk j in RUNS -- kRunBytes of every destination row of a tile row, then the next tile row, then the next run.
+    // The workgroups in flight on an XCD then write a few long contiguous runs (64 rows x 256 KiB) instead of one short run
+    // in very many rows (plain j first) or 512-byte pieces of 1024 rows (i first).  When the rows of consecutive batch planes
+    // are adjacent in the destination the planner has fused them into j (normalizeMove), so a run spans planes; if they are
+    // not fused (padded planes) the run is over batch planes instead (p1 bit 4).  Measured on the 8-GiB permutations, two
+    // boxes (profiles/r05_tuning.md): fp64 2.91-2.93 -> 2.81 ms, complex128 2.99 -> 2.86, fp32 2.89 -> 2.86; runs of
+    // 128 KiB ... 2 MiB are within 1 %.
+    c.p0 = 0;
+    const bool far_dst = aligned && c.stream == 2 && c.dm.ds[0] > 8 * c.dm.ss[1];
+    if (far_dst && !walk_forced) {
+      constexpr long long kRunBytes = 256 << 10;
+      const long long want = std::max<long long>(1, kRunBytes / ((long long)tj * es));  // tiles of one run
+      if ((long long)c.t1 >= 2 * want) {
+        long long run = want;
+        while (run > 1 && c.t1 % run != 0) --run;  // (a divisor of the tile count: the walk stays a plain mixed-radix number)
+        if (run >= want / 4 && run >= 4) {
+          c.p0 = (int)run;
+          j_first = true;
+        }
+      } else if (c.dm.e[2] > 1 && c.dm.ds[2] < c.dm.ds[0] && (long long)c.t1 * tj * es <= (64 << 10)) {
+        long long run = std::max<long long>(1, kRunBytes / std::max<long long>(1, c.dm.ds[2] * es));
+        while (run > 1 && c.dm.e[2] % run != 0) --run;
+        if (run >= 4) {
+          c.p0 = (int)run;
+          c.p1 |= 4;
+          j_first = true;
+        }
+      }
+    }
+    if (j_first) c.p1 |= 2;
+    c.blocks = (unsigned long long)c.t0 * c.t1 * (unsigned long long)c.dm.e[2];
+    return c;
+  }
+
+  c.cls = MOVE_GENERIC;
+  c.variant = es;
+  for (int i = 0; i < 3; ++i) {
+    c.dm.e[i] = m.extent[i];
+    c.dm.ss[i] = m.ss[i];
+    c.dm.ds[i] = m.ds[i];
+  }
+  c.p0 = 0;
+  for (int i = 0; i < 3; ++i)
+    if (m.ds[i] == 1 && m.extent[i] > 1) c.p0 = i;
+  const unsigned long long want = ((unsigned long long)c.elements + kThreads - 1) / kThreads;
+  c.blocks = std::min<unsigned long long>(std::max<unsigned long long>(want, 1), 8192);
+  return c;
+}
+
+char g_last_kernel[96] = "";
+
+void tileOf(int es, int variant, bool window, int* ti, int* tj) {
+  if (es == 16) {
+    *ti = 32;
+    *tj = variant == 301 ? 64 : 32;
+  } else if (window) {
+    *ti = variant >= 100 ? 128 : 64;
+    *tj = es == 4 ? 128 : 64;
+  } else {
+    *ti = variant == 204 ? 128 : 64;
+    *tj = (variant == 304 || variant == 302) ? 128 : 64;
+  }
+}
+
+void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bool window, int es, const Batch& b,
+                 unsigned int blocks, hipStream_t stream) {
+  // what ran last, in the words of the kernel templates (bench.py reports its dominant kernel from here)
+  int ti = 0, tj = 0;
+  tileOf(es, variant, window, &ti, &tj);
+  if (cls == MOVE_ROWS_VEC)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d>", window ? "rows_shifted_kernel" : "rows_kernel", variant,
+             stream_access == 3 ? 3 : (stream_access >= 1 ? 1 : 0));
+  else if (cls == MOVE_TRANSPOSE && window)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_window_kernel<%d,%d,%d,%d,%d>", es, variant % 100, ti, tj,
+             (stream_access == 2 || stream_access == 4) ? 4 : stream_access);
+  else if (cls == MOVE_TRANSPOSE)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_kernel<%d,%d,%d,%d,%d,%s>", es, variant % 100, ti, tj, stream_access,
+             swizzle ? "true" : "false");
+  else
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "generic_kernel<%d,%s>", es, stream_access == 3 ? "true" : "false");
+  switch (cls) {
+    case MOVE_ROWS_VEC:
+      launchRowsBatch(window, variant, stream_access, b, blocks, stream);
+      break;
+    case MOVE_TRANSPOSE:
+      if (window) launchWindowBatch(es, variant % 100, variant >= 100, stream_access, b, blocks, stream);
+      else if (es == 4) launchTransposeBatch4(variant, stream_access, swizzle, b, blocks, stream);
+      else if (es == 8) launchTransposeBatch8(variant, stream_access, swizzle, b, blocks, stream);
+      else launchTransposeBatch16(variant, stream_access, swizzle, b, blocks, stream);
+      break;
+    default:
+      launchGenericBatch(es, stream_access == 3, b, blocks, stream);
+      break;
+  }
+}
+
+}  // namespace
+
+const char* lastKernelName() { return g_last_kernel; }
+
+void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStream_t stream,
+                 const KernelTuning* tuning, KernelStats* stats, void* const* dst_base_override) {
+  const bool remote = dst_base_override != nullptr;
+  if (es != 4 && es != 8 && es != 16) CD_INTERNAL_ERROR("unsupported element size");
+  std::vector<Classified> cs;
+  cs.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    if (moves[i].elements() == 0) continue;
+    cs.push_back(classify(moves[i], bufs, es, tuning, dst_base_override ? dst_base_override[i] : nullptr, remote));
+  }
+  // moves of one phase are independent, so they may be regrouped by kernel flavour
+  std::vector<bool> done(cs.size(), false);
+  for (size_t i = 0; i < cs.size(); ++i) {
+    if (done[i]) continue;
+    Batch b{};
+    unsigned long long blocks = 0;
+    for (size_t j = i; j < cs.size() && b.n < kMaxBatch; ++j) {
+      if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant || cs[j].stream != cs[i].stream ||
+          cs[j].swizzle != cs[i].swizzle || cs[j].window != cs[i].window)
+        continue;
+      if (blocks + cs[j].blocks > 0x7fffffffULL) {
+        if (b.n == 0) CD_NOT_SUPPORTED("single block move too large for one launch");
+        break;
+      }
+      b.first_block[b.n] = (unsigned int)blocks;
+      b.m[b.n] = cs[j].dm;
+      b.p0[b.n] = cs[j].p0;
+      b.p1[b.n] = cs[j].p1;
+      b.t0[b.n] = cs[j].t0;
+      b.t1[b.n] = cs[j].t1;
+      blocks += cs[j].blocks;
+      if (stats) stats->elements[cs[j].cls] += cs[j].elements;
+      ++b.n;
+      done[j] = true;
+    }
+    b.first_block[b.n] = (unsigned int)blocks;
+    // Sibling row copies of one phase (the P chunks of an unpack, say) each touch one slice of every destination row:
+    // run one after the other, a 2-KiB slice of every 8-KiB row keeps part of the memory channels idle.  Served round
+    // robin, the workgroups in flight cover whole rows (C3 per-rank unpacks: 0.43-0.47 -> 0.35 ms, r02_tuning.md).
+    // Transposes keep their XCD-contiguous tile walk (interleaving them measured slightly slower).
+    const bool il_local = cs[i].cls != MOVE_TRANSPOSE && (!tuning || tuning->interleave_rows != 0);
+    if ((dst_base_override || il_local) && b.n > 1) {
+      unsigned long long widest = 0;
+      for (int k = 0; k < b.n; ++k) widest = std::max<unsigned long long>(widest, b.first_block[k + 1] - b.first_block[k]);
+      if (widest * b.n <= 0x7fffffffULL) {
+        b.interleave = 1;
+        blocks = widest * b.n;
+      }
+    }
+    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, cs[i].swizzle, cs[i].window, es, b, (unsigned int)blocks, stream);
+    if (stats) stats->launches[cs[i].cls] += 1;
+  }
+}
+
+}  // namespace cudecomp

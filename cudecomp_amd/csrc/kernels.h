@@ -1,4 +1,4 @@
-// kernels.h -- host entry points of the HIP data-movement kernels (kernels.hip).
+// kernels.h -- host entry points of the HIP data-movement kernels (kernels.cc: classification and batching; kernels_rows.hip, kernels_transpose.hip, kernels_window.hip: the kernels).
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -20,24 +20,16 @@ struct KernelStats {  // filled per launch when requested (tests, bench bookkeep
 };
 
 struct KernelTuning {
-  int force_class = -1;         // tests: force MOVE_GENERIC (2) to cross-check the fast paths
-  bool no_streaming = false;    // never use non-temporal access (CUDECOMP_DISABLE_STREAMING_ACCESS=1)
-  bool force_streaming = false; // tests: non-temporal access regardless of the move size
-  int stream_alignment = 0;        // tuning aid: alignment (bytes) below which transposes use cached access (0 = 128)
-  int lds_swizzle = -1;            // tuning aid: LDS tile layout of the transposes (1 swizzled, 0 padded, -1 per element size)
-  int walk_order = -1;             // tuning aid: transposes walk tiles i first (0) / j first (1); -1 = by strides
-  int misaligned_store_mode = -1;  // tuning aid: streaming mode (0/1/2) for transposes with unaligned destination rows
-  int stream_mode = -1;            // tuning aid: force the access mode (0..4, see kernels.hip) of large moves
-  int interleave_rows = 1;         // batched row copies: workgroups serve the moves round robin (0: one move after the other)
-  int window_wide = 0;             // window kernel, 8-byte elements: 1 = 128 x 64 tiles with 512 threads (CUDECOMP_WINDOW_WIDE=1)
-  int window_mode = -1;            // transposes onto rows off the 64-byte grid: -1 window kernel for moves >= 1 MiB, 0 never, 1 always
-  int local_store_policy = -1;     // diagnostic (CUDECOMP_LOCAL_STORE_POLICY): stores of LOCAL moves 0 cached, 1 non-temporal,
-                                   // 2 system-scope write-through + wait at the end of the kernel (as remote stores); -1 by size
-  int tile_shape = -1;             // 4-byte transposes with 16-byte lanes: 64 x 128 tiles (2: 512-byte destination segments; the
-                                   // default, -1), 64 x 64 (0) or 128 x 64 (1: 512-byte source segments); CUDECOMP_TILE_SHAPE.
-                                   // Measured on the 8-GiB fp32 cycle (profiles/r04_tuning.md): 11.22 / 11.69 / 11.69 ms
-  int xcd_walk = 1;                // diagnostic (CUDECOMP_XCD_WALK=0): transposes deal tiles round robin instead of one
-                                   // contiguous run of tiles per XCD
+  int force_class = -1;          // tests / CUDECOMP_FORCE_GENERIC_KERNELS: force MOVE_GENERIC (2) to cross-check the fast paths
+  bool no_streaming = false;     // never use non-temporal access (CUDECOMP_DISABLE_STREAMING_ACCESS=1)
+  bool force_streaming = false;  // tests: non-temporal access regardless of the move size
+  // tuning switches (read from the environment by `make TUNING_VARIANTS=1` builds only, csrc/api.cc):
+  int walk_order = -1;           // transposes walk tiles i first (0) / j first (1); -1 = by strides (CUDECOMP_TILE_WALK)
+  int interleave_rows = 1;       // batched row copies: workgroups serve the moves round robin (0: one move after the other)
+  int window_mode = -1;          // transposes onto rows off the 64-byte grid: -1 window kernel for moves >= 1 MiB, 0 never, 1 always
+  int window_wide = 0;           // window kernel, 8-byte elements: 1 = 128 x 64 tiles with 512 threads (CUDECOMP_WINDOW_WIDE=1)
+  int tile_shape = -1;           // 4-byte transposes with 16-byte lanes: 64 x 128 tiles (2, the default), 64 x 64 (0) or 128 x 64 (1);
+                                 // CUDECOMP_TILE_SHAPE; measured on the 8-GiB fp32 cycle (profiles/r04_tuning.md): 11.22 / 11.69 / 11.69 ms
 };
 
 // Execute `n` independent moves (disjoint destinations) of `es`-byte elements.  bufs[BufId] are the

@@ -5,7 +5,7 @@
 // Everything a transpose does locally is a Move3D:
 //     dst[dst_off + k0*ds[0] + k1*ds[1] + k2*ds[2]] = src[src_off + k0*ss[0] + k1*ss[1] + k2*ss[2]]
 // for 0 <= k_i < extent[i], all in ELEMENTS.  A pack, an unpack, a halo face copy and a full 3-D
-// permutation are the same object; the kernel layer (kernels.hip) picks the access pattern.
+// permutation are the same object; the kernel layer (kernels.cc + kernels_*.hip) picks the access pattern.
 //
 // What the plan must reproduce (bit-exact interior of the output pencil) is defined by
 // NVIDIA/cuDecomp's cudecompTranspose_ / cudecompUpdateHalos_ (reference

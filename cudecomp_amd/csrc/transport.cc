@@ -423,6 +423,9 @@ class PeerContext {
     if (!board_ || h_->nranks > 64 || !want || std::strtol(want, nullptr, 10) != 1) return;
     for (int r = 0; r < h_->nranks; ++r)
       if (h_->hostnames[r] != h_->hostnames[h_->rank]) return;  // (multi-node jobs keep the per-node board)
+    if (h_->rank == 0)
+      fprintf(stderr, "CUDECOMP:WARN: CUDECOMP_FLAGS_IN_DEVICE_MEMORY=1 is EXPERIMENTAL: not yet qualified with one GPU per rank "
+                      "(profiles/r05_tuning.md); the default keeps the flags in host-pinned memory.\n");
     const auto t_setup = std::chrono::steady_clock::now();
     struct Wire {
       hipIpcMemHandle_t handle;
@@ -820,6 +823,11 @@ std::vector<std::string> listDir(const std::string& path) {
 }
 }  // namespace
 
+bool peerQueueCensusRequested() {
+  const char* v = std::getenv("CUDECOMP_QUEUE_CENSUS");
+  return v && std::strtol(v, nullptr, 10) != 0;
+}
+
 int peerQueueCensus(cudecompHandle_t h, bool warn, int* slots_out) {
   // Which KFD node is my GPU?  (Not through my pid: inside a container's pid namespace getpid() is not the pid the driver
   // files my queues under.)  The topology node with my PCI location.
@@ -984,6 +992,10 @@ void peerMeasureLink(cudecompHandle_t h) {
     CD_CHECK_HIP(hipEventCreate(&e0));
     CD_CHECK_HIP(hipEventCreate(&e1));
     for (int engine = 0; engine < 2; ++engine) {
+#ifdef CUDECOMP_TUNING_VARIANTS  // (code-size bisect, scripts/probe/code_size_bisect.sh: probe with one engine only)
+      if (const char* only = std::getenv("CUDECOMP_LINK_PROBE_ENGINES"))
+        if ((engine == 0) != (std::strcmp(only, "sdma") == 0)) continue;
+#endif
       for (int rep = 0; rep < 3; ++rep) {  // rep 0 warms up (page mapping, code load)
         h->boot->barrier();
         CD_CHECK_HIP(hipEventRecord(e0, st));
@@ -1040,8 +1052,10 @@ void prepareTransports(cudecompHandle_t h, bool need_rccl, bool need_peer) {
     h->peer->agreePoolLimit();
     if (!h->boot->allreduceOr(!have_dev)) h->peer->setupDeviceFlags();  // (geometry-only jobs have no device)
     peerMeasureLink(h);
-    if (h->nranks > 1 && !h->link_crosses_devices && have_dev && !std::getenv("CUDECOMP_SKIP_QUEUE_CENSUS"))
-      (void)peerQueueCensus(h, true);  // ranks share a device
+    // Opt-in (CUDECOMP_QUEUE_CENSUS=1): count the compute queues of ALL processes on this GPU from the driver's tables and
+    // warn when they exceed the device's hardware queue slots (ranks sharing a GPU; profiles/r04_tuning.md).  Production --
+    // one process per GPU -- never comes near that, and reading the tables of every process is not free.
+    if (h->nranks > 1 && have_dev && peerQueueCensusRequested()) (void)peerQueueCensus(h, true);
   }
 }
 
@@ -1411,10 +1425,10 @@ bool peerRelayApplies(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
   return h->peer && gd->world.nranks == h->nranks && h->nranks <= kMaxFlags && h->peer->usable(gd->world);
 }
 
-void peerRelayEnsureRegion(cudecompHandle_t h, const RelayPlan& rp, int es) {
+bool peerRelayEnsureRegion(cudecompHandle_t h, const RelayPlan& rp, int es) {
   // the same number on every rank (it is derived from the whole decomposition), so this is collective by construction
   const size_t need = (size_t)rp.relayElements() * es;
-  if (h->relay_buf && h->relay_bytes >= need) return;
+  if (h->relay_buf && h->relay_bytes >= need) return true;
   if (h->relay_buf) workspaceFreeRaw(h, h->relay_buf);
   h->relay_buf = nullptr;
   h->relay_bytes = 0;
@@ -1423,11 +1437,17 @@ void peerRelayEnsureRegion(cudecompHandle_t h, const RelayPlan& rp, int es) {
   bool ok = r != nullptr;
   for (int g = 0; ok && g < h->nranks; ++g) ok = r->peer_base[g] != nullptr;
   if (h->boot->allreduceOr(!ok)) {
+    // agreed by all ranks: the relay is off for this handle from here on (no retry per call), exchanges go direct
     workspaceFreeRaw(h, p);
-    CD_PEER_ERROR("the relay region of the two-hop exchange could not be mapped into every rank of the node");
+    h->two_hop_relay = false;
+    if (h->rank == 0)
+      fprintf(stderr, "CUDECOMP:WARN: the relay region of the two-hop exchange could not be mapped into every rank of the node; "
+                      "CUDECOMP_TWO_HOP_RELAY is off for this handle.\n");
+    return false;
   }
   h->relay_buf = p;
   h->relay_bytes = need;
+  return true;
 }
 
 void peerRelayAlltoall(cudecompHandle_t h, cudecompCommInfo& world, const TransposePlan& p, const RelayPlan& rp,

@@ -42,6 +42,7 @@ void peerPoolCounters(cudecompHandle_t h, int64_t* pool_hits, int64_t* stale_map
 // (sysfs, /sys/class/kfd/kfd/proc/*/queues) and say so once when they exceed the device's hardware queue slots -- the
 // driver then time-slices every process of the device.  Best effort, never fails; returns the
 // count (-1 if the driver's tables are not readable) and the slots through *slots.
+bool peerQueueCensusRequested();  // CUDECOMP_QUEUE_CENSUS=1
 int peerQueueCensus(cudecompHandle_t h, bool warn, int* slots = nullptr);
 // throws if a device-side wait of an earlier one-sided exchange gave up (dead peer)
 void peerCheckStatus(cudecompHandle_t h);
@@ -89,7 +90,7 @@ PeerCall peerBegin(cudecompHandle_t h, cudecompCommInfo& ci, bool rendezvous, co
 // (collective).  Ordered on `stream`, nothing blocks the host.
 bool peerRelayApplies(cudecompHandle_t h, cudecompGridDesc_t gd, const TransposePlan& plan, cudecompTransposeCommBackend_t backend,
                       bool inplace);
-void peerRelayEnsureRegion(cudecompHandle_t h, const RelayPlan& rp, int es);
+bool peerRelayEnsureRegion(cudecompHandle_t h, const RelayPlan& rp, int es);
 void peerRelayAlltoall(cudecompHandle_t h, cudecompCommInfo& world, const TransposePlan& plan, const RelayPlan& rp,
                        const ExchangeBuffers& b, int es, const PeerCall& call, hipStream_t stream);
 

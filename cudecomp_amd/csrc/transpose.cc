@@ -1,5 +1,5 @@
 // transpose.cc -- executes transpose and halo plans: bind pointers, launch the move kernels, run the
-// exchange.  The algorithmic content lives in plan.cc (what moves where) and kernels.hip (how).
+// exchange.  The algorithmic content lives in plan.cc (what moves where) and kernels.cc / kernels_*.hip (how).
 #include <cstdio>
 
 #include "errors.h"
@@ -274,8 +274,13 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
                                                         &hp[6], &hp[9], inplace, traits, ci.npergroup)).first;
     }
     const RelayPlan& rp = rit->second;
-    if (rp.applies) {
-      peerRelayEnsureRegion(h, rp, es);
+    if (rp.applies && peerRelayEnsureRegion(h, rp, es)) {
+      // The relay region is ONE per handle and its slots are indexed by (source, chunk) only: relayed transposes of
+      // different descriptors or streams must not overlap on a rank.  Every relayed call therefore starts behind the
+      // previous one of this handle (an event per call); a peer's scatter into my region waits for my "begun", which I
+      // raise behind that event, i.e. after my previous forward has read the slots.
+      if (h->relay_last_call) CD_CHECK_HIP(hipStreamWaitEvent(stream, h->relay_last_call, 0));
+      else CD_CHECK_HIP(hipEventCreateWithFlags(&h->relay_last_call, hipEventDisableTiming));
       call = peerBegin(h, gd->world, false, xb.recv, output, false, stream);
       gd->path_count[xpath]++;
       gd->relayed++;
@@ -285,6 +290,7 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
       perfMark(pev, 2, stream);
       launchMoves(plan.unpack.data(), (int)plan.unpack.size(), bufs, es, stream, &h->tuning);
       perfMark(pev, 3, stream);
+      CD_CHECK_HIP(hipEventRecord(h->relay_last_call, stream));
       return;
     }
   }

@@ -200,7 +200,7 @@ typedef struct {
 } cudecompExtLinkInfo_t;
 cudecompResult_t cudecompExtGetLinkInfo(cudecompHandle_t handle, cudecompExtLinkInfo_t* info);
 
-/* Name of the data-movement kernel this process launched last, as its template is spelled in csrc/kernels.hip (e.g.
+/* Name of the data-movement kernel this process launched last, as its template is spelled in csrc/kernels_*.hip (e.g.
  * "transpose_kernel<8,2,64,64,2,true>"); "" before the first launch.  The string is owned by the library. */
 const char* cudecompExtLastKernelName(void);
 

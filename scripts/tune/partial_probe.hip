@@ -114,7 +114,13 @@ int main() {
                {"pitch 8208, dst +8 B, src +8 B (halo pencil to halo pencil)", 8208, 8, 8},
                {"pitch 8208, dst +8 B, src aligned rows (pitch 8192)", 8208, 8, -1},
                {"pitch 8256 (64-B multiple), dst +8 B, src +8 B", 8256, 8, 8},
-               {"pitch 8208, dst +0 (rows drift over the grid, first row aligned)", 8208, 0, 0}};
+               {"pitch 8208, dst +0 (rows drift over the grid, first row aligned)", 8208, 0, 0},
+               {"pitch 8320 = 65 lines: rows line-aligned, 128-B holes between rows", 8320, 0, 0},
+               {"pitch 8256: rows unit-aligned (every other row starts mid-line), 64-B holes", 8256, 0, 0},
+               {"pitch 8192, dst +8 B, src +8 B: dense, everything 8 B off the grid (no holes)", 8192, 8, 8},
+               {"pitch 8192, dst +64 B, src +64 B: dense, half a line off", 8192, 64, 64},
+               {"pitch 8192, dst +0, src +8 B: only the loads off the grid", 8192, 0, 8},
+               {"pitch 8192, dst +8, src +0 B: only the stores off the grid (lanes on the dst grid)", 8192, 8, 0}};
   for (auto& c : cases) {
     printf("== %s\n", c.name);
     // (soff -1: the source uses its own dense pitch; emulated by giving the source the same pitch but offset 0 -- the loads

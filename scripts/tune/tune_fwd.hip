@@ -1,17 +1,23 @@
 // tune_fwd.hip -- round 5: the forward hops of the 1024^3 axis-contiguous cycle (destination rows 8 MiB apart) against the
-// inverse ones (source rows 8 MiB apart), with the LIBRARY's own tile code (this file includes csrc/kernels.hip, so every
+// inverse ones (source rows 8 MiB apart), with the LIBRARY's own tile code (this file includes csrc/kernels_tile.h, so every
 // variant here is the shipped transposeTile / transposeTilePadded with other template arguments or another tile walk; nothing
 // is added to the library's device code).  Not part of the product.
 //
-//   build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../cudecomp_amd/csrc -I../../include tune_fwd.hip \
-//               ../../cudecomp_amd/csrc/plan.cc ../../cudecomp_amd/csrc/decomp.cc -o tune_fwd
+//   build:  make -C ../../cudecomp_amd && hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../cudecomp_amd/csrc -I../../include tune_fwd.hip \
+//               ../../cudecomp_amd/build/{kernels,plan,decomp}.o ../../cudecomp_amd/build/kernels_*.hip.o -o tune_fwd
 //   run:    ./tune_fwd [8|16] [reps]
 //
 // Sections: (1) tile shapes x access modes x tile walks, per direction; (2) the same launch isolated (host sync between
 // launches) and sustained (back to back, events between launches): where the time between kernels goes.
-#include "kernels.hip"
+#include "kernels_tile.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 using namespace cudecomp;
+using namespace cudecomp::kern;
 
 #define CK(x)                                                          \
   do {                                                                 \
@@ -113,7 +119,8 @@ static double g_bytes = 0;
     fflush(stdout);                                                                                                        \
   }
 
-static float libLaunch(const Shape& s, char* src, char* dst, int es, int reps, bool sustained, float* per_launch) {
+static float libLaunch(const Shape& s, char* src, char* dst, int es, int reps, bool sustained, float* per_launch,
+                       const KernelTuning* tuning = nullptr) {
   Move3D m;
   m.src_buf = BUF_IN;
   m.dst_buf = BUF_OUT;
@@ -123,13 +130,13 @@ static float libLaunch(const Shape& s, char* src, char* dst, int es, int reps, b
   void* bufs[3] = {src, dst, nullptr};
   std::vector<hipEvent_t> ev(reps + 1);
   for (auto& evt : ev) CK(hipEventCreate(&evt));
-  launchMoves(&m, 1, bufs, es, nullptr);
+  launchMoves(&m, 1, bufs, es, nullptr, tuning);
   CK(hipDeviceSynchronize());
   float total = 0;
   if (sustained) {
     CK(hipEventRecord(ev[0]));
     for (int r = 0; r < reps; ++r) {
-      launchMoves(&m, 1, bufs, es, nullptr);
+      launchMoves(&m, 1, bufs, es, nullptr, tuning);
       CK(hipEventRecord(ev[r + 1]));
     }
     CK(hipDeviceSynchronize());
@@ -140,7 +147,7 @@ static float libLaunch(const Shape& s, char* src, char* dst, int es, int reps, b
   } else {
     for (int r = 0; r < reps; ++r) {
       CK(hipEventRecord(ev[0]));
-      launchMoves(&m, 1, bufs, es, nullptr);
+      launchMoves(&m, 1, bufs, es, nullptr, tuning);
       CK(hipEventRecord(ev[1]));
       CK(hipDeviceSynchronize());
       CK(hipEventElapsedTime(&per_launch[r], ev[0], ev[1]));
@@ -154,16 +161,17 @@ static float libLaunch(const Shape& s, char* src, char* dst, int es, int reps, b
 int main(int argc, char** argv) {
   const int es = argc > 1 ? atoi(argv[1]) : 8;
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
-  const long long N = 1024, NZ = es == 16 ? 512 : 1024, E = N * N * NZ;
+  const int phase = argc > 3 ? atoi(argv[3]) : 1;
+  // 8-GiB pencils: fp64 / complex64 1024^3, complex128 1024 x 1024 x 512, fp32 2048 x 1024 x 1024 (as bench.py's dtype table)
+  const long long NX = es == 4 ? 2048 : 1024, NY = 1024, NZ = es == 16 ? 512 : 1024, E = NX * NY * NZ;
   char *src, *dst;
   CK(hipMalloc(&src, E * es));
   CK(hipMalloc(&dst, E * es));
   CK(hipMemset(src, 1, E * es));
   g_bytes = 2.0 * E * es;
-  // fwd (X->Y, Y->Z): i -> stride N*NZ out (far), j contiguous out, k -> stride N out.   Source rows N apart.
-  // bwd (Z->Y, Y->X): source rows N*NZ apart (far), i -> stride N out.
-  // (for the 16-byte case the pencil is 1024 x 1024 x 512: the far stride is 8 MiB there too)
-  Shape shapes[2] = {{"fwd", N, N, NZ, N, N * N, N * NZ, N}, {"bwd", N, NZ, N, N * N, N, NZ, N * NZ}};
+  // fwd (X->Y): source (x, y, z), destination (y, z, x): i = x -> stride NY*NZ out (far), j = y contiguous out, k = z -> stride NY out.
+  // bwd (Y->X): source (y, z, x), destination (x, y, z): i = y, j = x (source stride NY*NZ: far), k = z.
+  Shape shapes[2] = {{"fwd", NX, NY, NZ, NX, NX * NY, NY * NZ, NY}, {"bwd", NY, NX, NZ, NY * NZ, NY, NX, NX * NY}};
   printf("# element size %d B, %.2f GB per launch, %d launches per figure; ms per launch (fraction of 8 TB/s), fwd | bwd\n", es, g_bytes / 1e9, reps);
   {
     float pl[64];
@@ -179,8 +187,20 @@ int main(int argc, char** argv) {
                s.name, lastKernelName(), iso, mn, mx, sus, pl[0], smn, smx, (sus - iso) * 1e3);
       }
   }
+  {  // the library with its tile walk forced (tuning switch): 0 = i first, 1 = j first
+    float pl[64];
+    for (int wo = 0; wo < 2; ++wo) {
+      KernelTuning t;
+      t.walk_order = wo;
+      const float f = libLaunch(shapes[0], src, dst, es, reps, true, pl, &t);
+      const float b = libLaunch(shapes[1], src, dst, es, reps, true, pl, &t);
+      printf("library with walk_order=%d (%s first): fwd %.3f ms, bwd %.3f ms\n", wo, wo ? "j" : "i", f, b);
+    }
+  }
   printf("| tile i x j | mode | LDS | walk | fwd ms (frac) | bwd ms (frac) |\n|---|---|---|---|---|---|\n");
-  if (es == 8) {
+  // walks: letters least significant first; i / j = tile index along i / j, k = the batch dim, l / h = low (KL values) and high
+  // part of k
+  if (es == 8 && phase == 1) {
     for (int rep = 0; rep < 2; ++rep) {
       ROW(8, 2, 64, 64, 2, true, "jik", 1, 1)   // the library's default for fp64
       ROW(8, 2, 64, 64, 2, true, "ijk", 1, 1)
@@ -205,19 +225,82 @@ int main(int argc, char** argv) {
       ROW(8, 2, 32, 64, 2, true, "jik", 1, 1)
       ROW(8, 2, 64, 32, 2, true, "jik", 1, 1)
     }
-  } else {
+  } else if (es == 8 && phase == 3) {
+    for (int rep = 0; rep < 2; ++rep) {
+      ROW(8, 2, 64, 64, 2, true, "jik", 1, 1)
+      ROW(8, 2, 64, 64, 2, true, "ijk", 1, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlih", 32, 0)
+      ROW(8, 2, 64, 64, 2, true, "ajlbh", 2, 1)   // (a / l share KL here: 2 i tiles, then j, then 2 planes ...)
+      ROW(8, 2, 64, 64, 2, true, "jalbh", 4, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlabh", 4, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlabh", 8, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlabh", 16, 1)
+      ROW(8, 2, 64, 128, 2, true, "ijk", 1, 1)
+      ROW(8, 2, 64, 128, 2, true, "iljh", 32, 1)
+    }
+  } else if (es == 8) {  // phase 2: around the winners of phase 1 (fwd: 64 x 64 j, 32 k planes, i; 128 x 32 -- bwd: 64 x 128)
+    for (int rep = 0; rep < 2; ++rep) {
+      ROW(8, 2, 64, 64, 2, true, "jik", 1, 1)
+      ROW(8, 2, 64, 64, 2, true, "ijk", 1, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlih", 16, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlih", 64, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlih", 128, 1)
+      ROW(8, 2, 64, 64, 2, true, "jlih", 256, 1)
+      ROW(8, 2, 64, 64, 2, true, "iljh", 8, 1)   // the mirror for far-strided SOURCE rows: i, then k planes, then j
+      ROW(8, 2, 64, 64, 2, true, "iljh", 32, 1)
+      ROW(8, 2, 64, 64, 2, true, "iljh", 128, 1)
+      ROW(8, 2, 64, 64, 2, true, "ikj", 1, 1)
+      ROW(8, 2, 128, 32, 2, true, "ijk", 1, 1)
+      ROW(8, 2, 128, 32, 2, true, "jik", 1, 1)
+      ROW(8, 2, 128, 32, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 128, 32, 2, true, "iljh", 32, 1)
+      ROW(8, 2, 256, 16, 2, true, "ijk", 1, 1)
+      ROW(8, 2, 64, 128, 2, true, "ijk", 1, 1)
+      ROW(8, 2, 64, 128, 2, true, "jik", 1, 1)
+      ROW(8, 2, 64, 128, 2, true, "iljh", 32, 1)
+      ROW(8, 2, 64, 128, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 64, 128, 4, true, "ijk", 1, 1)
+      ROW(8, 2, 32, 256, 2, true, "ijk", 1, 1)
+      ROW(8, 2, 32, 256, 2, true, "jik", 1, 1)
+    }
+  } else if (es == 16) {
     for (int rep = 0; rep < 2; ++rep) {
       ROW(16, 1, 32, 32, 2, false, "jik", 1, 1)  // the library's default for 16-byte elements
       ROW(16, 1, 32, 32, 2, false, "ijk", 1, 1)
       ROW(16, 1, 32, 32, 2, false, "jlih", 8, 1)
+      ROW(16, 1, 32, 32, 2, false, "jlih", 16, 1)
+      ROW(16, 1, 32, 32, 2, false, "jlih", 32, 1)
+      ROW(16, 1, 32, 32, 2, false, "jlih", 64, 1)
+      ROW(16, 1, 32, 32, 2, false, "iljh", 32, 1)
       ROW(16, 1, 32, 64, 2, false, "jik", 1, 1)  // 1-KiB destination segments
       ROW(16, 1, 32, 64, 2, false, "ijk", 1, 1)
+      ROW(16, 1, 32, 64, 2, false, "iljh", 32, 1)
       ROW(16, 1, 64, 32, 2, false, "jik", 1, 1)
       ROW(16, 1, 64, 32, 2, false, "ijk", 1, 1)
+      ROW(16, 1, 64, 32, 2, false, "jlih", 32, 1)
       ROW(16, 1, 64, 64, 2, false, "jik", 1, 1)
+      ROW(16, 1, 64, 64, 2, false, "ijk", 1, 1)
       ROW(16, 1, 16, 64, 2, false, "jik", 1, 1)
-      ROW(16, 1, 32, 32, 4, false, "jik", 1, 1)
-      ROW(16, 1, 32, 32, 2, true, "jik", 1, 1)
+      ROW(16, 1, 64, 16, 2, false, "ijk", 1, 1)
+      ROW(16, 1, 64, 16, 2, false, "jlih", 32, 1)
+    }
+  } else {  // 4-byte elements (library default: 64 x 128 tiles; i first when the far-strided side is the destination)
+    for (int rep = 0; rep < 2; ++rep) {
+      ROW(4, 4, 64, 128, 2, true, "jik", 1, 1)
+      ROW(4, 4, 64, 128, 2, true, "ijk", 1, 1)
+      ROW(4, 4, 64, 128, 2, true, "jlih", 32, 1)
+      ROW(4, 4, 64, 128, 2, true, "jlih", 8, 1)
+      ROW(4, 4, 64, 128, 2, true, "iljh", 32, 1)
+      ROW(4, 4, 128, 64, 2, true, "ijk", 1, 1)
+      ROW(4, 4, 128, 64, 2, true, "jlih", 32, 1)
+      ROW(4, 4, 128, 128, 2, true, "jik", 1, 1)
+      ROW(4, 4, 128, 128, 2, true, "ijk", 1, 1)
+      ROW(4, 4, 64, 256, 2, true, "ijk", 1, 1)
+      ROW(4, 4, 64, 256, 2, true, "jik", 1, 1)
+      ROW(4, 4, 256, 64, 2, true, "ijk", 1, 1)
+      ROW(4, 4, 256, 32, 2, true, "ijk", 1, 1)
     }
   }
   return 0;

@@ -1,5 +1,5 @@
 """HIP kernel parity, move by move: cudecompExtMove3D (rows / LDS-transpose / generic kernels of
-cudecomp_amd/csrc/kernels.hip) against the numpy restatement in oracle/ on the same seeded inputs.
+cudecomp_amd/csrc/kernels_*.hip, dispatched by kernels.cc) against the numpy restatement in oracle/ on the same seeded inputs.
 Bit-exact (pure data movement, tolerance 0)."""
 import itertools
 
@@ -78,6 +78,17 @@ def test_transpose_vector_and_scalar_paths(es):
         ds = (ej + 4 * vw, 1, (ej + 4 * vw) * ei)
         run_move(es, (ei, ej, ek), sin, ds, off + sin[2] * ek + 64, off + ds[2] * ek + 64, off, off, seed=ei + off,
                  expect_cls=1)
+
+
+@pytest.mark.parametrize("es", [4, 8, 16])
+def test_transpose_far_strided_destination_walk(es):
+    """Forward hops of an axis-contiguous cycle: destination rows far apart (stride ei-independent, >= 8 source rows), their
+    batch planes adjacent -- the tile walk then visits j, a run of batch planes, i (kernels.cc classify(), "far-strided
+    destination").  Batch extents that hold runs of 32 / 16 / 4 planes and one that holds none, edge tiles included."""
+    for ei, ej, ek in [(128, 64, 64), (192, 128, 48), (64, 64, 36), (64, 64, 30), (130, 64, 32), (128, 70, 32)]:
+        sin = (1, ei, ei * ej)           # source (x, y, z)
+        ds = (ej * ek, 1, ej)            # destination (y, z, x): x slowest
+        run_move(es, (ei, ej, ek), sin, ds, ei * ej * ek + 8, ei * ej * ek + 8, seed=ei + ek, expect_cls=1)
 
 
 def test_degenerate_and_gather_moves():

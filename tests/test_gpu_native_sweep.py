@@ -19,6 +19,10 @@ pytestmark = pytest.mark.gpu
 PERMS = [" ".join(map(str, p)) for p in itertools.permutations((0, 1, 2))]
 PDIMS = [(1, 4), (2, 2), (4, 1)]
 Z = "0 0 0"
+# switches that only the `make TUNING_VARIANTS=1` build of the library reads (csrc/api.cc: tuningSwitch)
+TUNING_SWITCHES = {"CUDECOMP_INTERLEAVE_ROWS", "CUDECOMP_WINDOW_STORES", "CUDECOMP_WINDOW_WIDE", "CUDECOMP_TILE_WALK",
+                   "CUDECOMP_TILE_SHAPE"}
+TUNING_LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cudecomp_amd", "lib_tuning")
 
 
 def _tcase(pr, pc, backend, gd=Z, hx=Z, hy=Z, hz=Z, px=Z, py=Z, pz=Z, extra="", oop=False):
@@ -151,7 +155,12 @@ def test_sweep_eight_ranks():
                               "no_workspace_pool"])
 def test_sweep_library_switches_do_not_change_results(env):
     """Environment switches of the library (graph capture of the pipelined pack loop, the performance report, kernel
-    tuning / debug switches) on a slice of the base sweep: results stay exact."""
+    tuning / debug switches) on a slice of the base sweep: results stay exact.  Tuning switches exist only in the
+    `make TUNING_VARIANTS=1` build of the library (cudecomp_amd/lib_tuning): those entries run against it."""
+    if TUNING_SWITCHES & set(env):
+        if not os.path.exists(os.path.join(TUNING_LIB_DIR, "libcudecomp.so")):
+            pytest.skip("cudecomp_amd/lib_tuning not built (make -C cudecomp_amd TUNING_VARIANTS=1)")
+        env = dict(env, LD_LIBRARY_PATH=TUNING_LIB_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     _switch_sweep(env)
 
 
