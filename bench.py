@@ -344,7 +344,7 @@ def run_cycles(cd, torch, dist, world, h, gd, pen, inplace, warmup, steps, strea
     for _ in range(warmup):
         cycle()
     torch.cuda.synchronize()
-    op_ms = []
+    op_ms, op_kernels = [], []
     cur, nxt = pen.a, (pen.a if inplace else pen.b)
     for op in cd.OPS:  # per-op split, outside the timed region
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -353,8 +353,28 @@ def run_cycles(cd, torch, dist, world, h, gd, pen, inplace, warmup, steps, strea
         e1.record()
         torch.cuda.synchronize()
         op_ms.append(e0.elapsed_time(e1))
+        op_kernels.append(cd.cudecompExtLastKernelName())
         if not inplace:
             cur, nxt = nxt, cur
+    # the same split INSIDE a sustained sequence (no host synchronisation between the hops; outside the timed region): events
+    # between the hops of 3 back-to-back cycles after one more warm-up cycle.  Isolated hops start on an idle memory system;
+    # sustained ones inherit the previous hop's tail (dirty lines of the 256 MB memory-side cache still draining to HBM).
+    op_sus = [0.0] * len(cd.OPS)
+    sus_cycles = 3
+    cycle()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(sus_cycles * len(cd.OPS) + 1)]
+    marks[0].record()
+    for c in range(sus_cycles):
+        cur, nxt = pen.a, (pen.a if inplace else pen.b)
+        for i, op in enumerate(cd.OPS):
+            cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), pen.work, cd.DOUBLE, stream=stream)
+            marks[c * len(cd.OPS) + i + 1].record()
+            if not inplace:
+                cur, nxt = nxt, cur
+    torch.cuda.synchronize()
+    for c in range(sus_cycles):
+        for i in range(len(cd.OPS)):
+            op_sus[i] += marks[c * len(cd.OPS) + i].elapsed_time(marks[c * len(cd.OPS) + i + 1]) / sus_cycles
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     barrier()
     torch.cuda.synchronize()
@@ -377,7 +397,8 @@ def run_cycles(cd, torch, dist, world, h, gd, pen, inplace, warmup, steps, strea
         cyc_all = [x for c in allc for x in c]
     else:
         cyc_all = cyc
-    return {"wall_ms": wall_ms, "cycle_ms": cyc, "cycle_ms_all_ranks": cyc_all, "op_ms": op_ms, "ok": ok}
+    return {"wall_ms": wall_ms, "cycle_ms": cyc, "cycle_ms_all_ranks": cyc_all, "op_ms": op_ms, "op_ms_sustained": op_sus, "op_kernels": op_kernels,
+            "ok": ok}
 
 
 def extras_single_gpu(cd, torch, h, stream):
@@ -491,7 +512,8 @@ def dtype_table(cd, torch, h, stream, only=None):
                     per_op.append({"op": op, "ms": round(avg, 4), "ms_min": round(min(ms[op]), 4), "ms_max": round(max(ms[op]), 4),
                                    "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "kernel": kernels[op]})
                 row["per_op"] = per_op
-                row["cycle_ms"] = round(sum(o["ms"] for o in per_op), 4)
+                row["cycle_ms"] = round(sum(o["ms"] for o in per_op), 4)  # SUM OF HOPS timed one at a time, not a sustained cycle
+                row["cycle_ms_is"] = "sum of the per-hop medians (each hop timed alone)"
                 row["min_frac"] = min(o["frac"] for o in per_op)
                 del a, b, keep
                 cd.cudecompFree(h, gd, work)
@@ -698,6 +720,7 @@ def main():
                                       "in-place" if args.inplace else "out-of-place"),
                        "pdims": list(pdims), "transport": m["used"], "autotuned": m["autotuned"],
                        "per_op_ms": [round(x, 4) for x in head["op_ms"]], "per_op_split": m["split"],
+                       "per_op_ms_sustained": [round(x, 4) for x in head.get("op_ms_sustained", [])],
                        "round_trip_checksum_ok": bool(m["ok"]), "fallback": fallback,
                        "direct_puts": m["counters"]["direct_puts"]},
             # protocol of SURVEY 8(d): per-cycle device times (HIP events on the library's stream) over the timed cycles of
@@ -735,10 +758,33 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": (src + " (rocprofv3 PMC passes of this command; counters cannot run inside the "
                                        "timed loop)") if src else None,
-                    "kernel": m["kernel"], "kernel_source": "cudecompExtLastKernelName() after the timed cycles",
+                    "kernel": m["kernel"], "kernel_source": "cudecompExtLastKernelName() after every hop of one extra cycle",
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                     "launches_per_cycle": launches_per_cycle,
                     "duration_source": "HIP events on the library's stream around each timed cycle"}
+            # where a cycle's time is: the kernels one at a time (each hop alone between two host synchronisations), the
+            # same hops inside a sustained sequence (events between them, no host synchronisation), and what is left
+            iso, sus = sum(head["op_ms"]), sum(head.get("op_ms_sustained", []))
+            cyc_ms = sum(head["cycle_ms"]) / len(head["cycle_ms"])
+            roof["kernel_sum_ms"] = round(iso, 4)
+            roof["sustained_hop_sum_ms"] = round(sus, 4)
+            roof["gap_ms"] = round(cyc_ms - iso, 4)
+            roof["gap_note"] = ("kernel_sum_ms = the hops of one cycle timed ONE AT A TIME (host synchronisation before each); "
+                                "sustained_hop_sum_ms = the same hops inside back-to-back cycles (events between them, no host "
+                                "synchronisation); gap_ms = timed cycle - kernel_sum_ms.  rocprofv3 begin / end timestamps of the same "
+                                "command (profiles/r05_cycle_gaps.json): median idle time between one kernel's end and the next "
+                                "one's begin 0 us, back-to-back kernels not slower than isolated ones")
+            if not args.inplace and head.get("op_kernels"):
+                # the hops of a cycle may run different instantiations (round 5: forward and inverse hops use different tiles /
+                # tile walks); `achieved` is the average over the launches of a cycle, the per-kernel figures come from the
+                # sustained per-hop events
+                per_k = {}
+                for name, ms_ in zip(head["op_kernels"], head.get("op_ms_sustained", [])):
+                    per_k.setdefault(name, []).append(ms_)
+                roof["kernel"] = " + ".join(sorted(per_k)) if per_k else roof["kernel"]
+                roof["per_kernel"] = [{"kernel": k, "launches_per_cycle": len(v), "avg_launch_ms": round(sum(v) / len(v), 4),
+                                       "achieved": round(alg_bytes / (sum(v) / len(v) * 1e-3) / 1e9, 1),
+                                       "frac": round(alg_bytes / (sum(v) / len(v) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)} for k, v in sorted(per_k.items())]
             if args.layout == "contiguous" and not args.inplace:
                 # context for `frac`: what a plain copy of the same pencil reaches on this GPU right now (the library's
                 # row-copy kernel on the same buffers: X->Y of a 1x1 grid in the default layout), outside the timed region

@@ -187,6 +187,44 @@ int main(int argc, char** argv) {
                s.name, lastKernelName(), iso, mn, mx, sus, pl[0], smn, smx, (sus - iso) * 1e3);
       }
   }
+  {  // the four hops of a cycle back to back with ping-pong buffers (what bench.py times), events between the hops
+    auto mk = [&](const Shape& sh) {
+      Move3D m;
+      m.src_buf = BUF_IN; m.dst_buf = BUF_OUT;
+      m.extent[0] = sh.ei; m.extent[1] = sh.ej; m.extent[2] = sh.ek;
+      m.ss[0] = 1; m.ss[1] = sh.sj; m.ss[2] = sh.sk;
+      m.ds[0] = sh.di; m.ds[1] = 1; m.ds[2] = sh.dk;
+      return m;
+    };
+    const Move3D mv[4] = {mk(shapes[0]), mk(shapes[0]), mk(shapes[1]), mk(shapes[1])};
+    const int cycles = 6;
+    std::vector<hipEvent_t> ev(4 * cycles + 1);
+    for (auto& evt : ev) CK(hipEventCreate(&evt));
+    for (int pass = 0; pass < 2; ++pass) {
+      char *a = src, *b2 = dst;
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(ev[0]));
+      for (int c = 0; c < cycles; ++c)
+        for (int hh = 0; hh < 4; ++hh) {
+          void* bufs[3] = {a, b2, nullptr};
+          launchMoves(&mv[hh], 1, bufs, es, nullptr);
+          CK(hipEventRecord(ev[4 * c + hh + 1]));
+          std::swap(a, b2);
+        }
+      CK(hipDeviceSynchronize());
+      float hop[4] = {0, 0, 0, 0}, total = 0;
+      for (int c = 1; c < cycles; ++c)
+        for (int hh = 0; hh < 4; ++hh) {
+          float t;
+          CK(hipEventElapsedTime(&t, ev[4 * c + hh], ev[4 * c + hh + 1]));
+          hop[hh] += t / (cycles - 1);
+          total += t / (cycles - 1);
+        }
+      printf("ping-pong cycle (fwd fwd bwd bwd, events between hops, %d cycles after one warm-up): hops %.3f %.3f %.3f %.3f ms, cycle %.3f ms\n",
+             cycles - 1, hop[0], hop[1], hop[2], hop[3], total);
+    }
+    for (auto& evt : ev) CK(hipEventDestroy(evt));
+  }
   {  // the library with its tile walk forced (tuning switch): 0 = i first, 1 = j first
     float pl[64];
     for (int wo = 0; wo < 2; ++wo) {
