@@ -355,3 +355,25 @@ def test_every_code_object_stays_small():
         sizes = _code_objects(lib)
         assert len(sizes) >= 5, sizes
         assert max(sizes) < 400_000, "a code object of %s grew to %d bytes: split its translation unit" % (name, max(sizes))
+
+
+def test_tuning_switches_are_ignored_loudly_by_the_default_build():
+    """Tuning switches (tile walks, tile shapes, window variants) and the kernel variants they select exist in `make
+    TUNING_VARIANTS=1` builds only (cudecomp_amd/lib_tuning).  The default build must not follow them silently (an A/B made with
+    it would be misattributed): cudecompInit says once, on rank 0, that the switch is ignored."""
+    import subprocess
+    import sys
+    code = "import cudecomp_amd as cd; h = cd.cudecompInit(); cd.cudecompFinalize(h)"
+    env = dict(os.environ, CUDECOMP_TILE_WALK="0", CUDECOMP_WINDOW_WIDE="1", PYTHONPATH=ROOT)
+    env.pop("CUDECOMP_AMD_LIBRARY", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = r.stdout + r.stderr
+    assert "CUDECOMP:WARN: CUDECOMP_TILE_WALK is a tuning switch" in text, text[-2000:]
+    assert "CUDECOMP:WARN: CUDECOMP_WINDOW_WIDE is a tuning switch" in text
+    tuning = os.path.join(ROOT, "cudecomp_amd", "lib_tuning", "libcudecomp.so")
+    if os.path.exists(tuning):  # the tuning build reads them and stays quiet
+        r = subprocess.run([sys.executable, "-c", code], env=dict(env, CUDECOMP_AMD_LIBRARY=tuning), capture_output=True, text=True,
+                           timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "tuning switch" not in r.stdout + r.stderr
