@@ -72,6 +72,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     if (rank == worldSize() - 1 && std::getenv("CUDECOMP_TEST_INJECT_STALE_INPUT"))  // self-check of the gate
       T_CHECK_HIP(hipMemset(data + p.size / 2, 0xEE, std::min<int64_t>(100, p.size / 2) * sizeof(elem_t)));
     const bool stale_input = InputGate::get().checkInput("halo", data, init, p.size, 0);
+    if (stale_input) ++failures;  // a case whose input never arrived proves nothing about the library: it fails, loudly (DIAG line)
     bool pb[3] = {periods[0], periods[1], periods[2]};
     for (int dim = 0; dim < 3; ++dim) {
       if (axis == 0) T_CHECK_CD(cudecompUpdateHalosX(handle, gdesc, data, work, kDtype, halo.data(), pb, dim, pad.data(), 0));

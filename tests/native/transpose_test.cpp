@@ -86,6 +86,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     if (rank == worldSize() - 1 && std::getenv("CUDECOMP_TEST_INJECT_STALE_INPUT"))  // self-check of the gate
       T_CHECK_HIP(hipMemset(data + p[0].size / 2, 0xEE, std::min<int64_t>(100, p[0].size / 2) * sizeof(elem_t)));
     const bool stale_input = InputGate::get().checkInput("XToY", data, ref[0], p[0].size, 0);
+    if (stale_input) ++failures;  // a case whose input never arrived proves nothing about the library: it fails, loudly (DIAG line)
     phaseTimes().mark(2);
 
     struct Hop {
