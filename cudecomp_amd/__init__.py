@@ -142,7 +142,8 @@ EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecom
                "cudecompExtGetTransposeTimings", "cudecompExtGetHaloTimings", "cudecompExtPeerProbe", "cudecompExtGetCounters",
                "cudecompExtPlanTranspose", "cudecompExtPlanHalo", "cudecompExtPencilInfo", "cudecompExtShiftedRank",
                "cudecompExtWorkspaceSizes", "cudecompExtGetLinkInfo", "cudecompExtLastKernelName",
-               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs", "cudecompExtTrimWorkspacePool", "cudecompExtPlanRelay", "cudecompExtQueueCensus"]
+               "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs", "cudecompExtTrimWorkspacePool", "cudecompExtPlanRelay", "cudecompExtQueueCensus",
+               "cudecompExtDescribeMove"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -227,6 +228,8 @@ def lib():
         L.cudecompExtLastKernelName.argtypes = []
         L.cudecompExtLastKernelName.restype = C.c_char_p
         L.cudecompExtMove3D.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32, pi32, vp]
+        L.cudecompExtDescribeMove.argtypes = [C.c_uint64, C.c_uint64, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32,
+                                              C.POINTER(i64)]
         _lib = L
     return _lib
 
@@ -500,6 +503,16 @@ def cudecompExtMove3D(src, dst, es, extent, ss, ds, force_generic=False, stream=
     _check(lib().cudecompExtMove3D(src, dst, es, a(extent), a(ss), a(ds), int(force_generic), C.byref(cls), stream),
            "cudecompExtMove3D")
     return cls.value
+
+
+def cudecompExtDescribeMove(src_address, dst_address, es, extent, ss, ds, flags=0):
+    """How the kernel layer would run a move (no launch, no GPU): dict of class, variant, tile, tile counts, walk, access mode."""
+    a = lambda v: (C.c_int64 * 3)(*[int(x) for x in v])
+    out = (C.c_int64 * 10)()
+    _check(lib().cudecompExtDescribeMove(int(src_address), int(dst_address), es, a(extent), a(ss), a(ds), int(flags), out),
+           "cudecompExtDescribeMove")
+    keys = ("cls", "variant", "tile_i", "tile_j", "tiles_i", "tiles_j", "batch", "run", "walk", "access")
+    return dict(zip(keys, [int(x) for x in out]))
 
 
 def make_config(gdims, pdims, gdims_dist=None, rank_order=0, axis_contiguous=(0, 0, 0), mem_order=None,

@@ -510,6 +510,32 @@ cudecompResult_t cudecompExtRunLocalPhases(const cudecompExtGridSpec_t* grid, in
   return CUDECOMP_RESULT_SUCCESS;
 }
 
+cudecompResult_t cudecompExtDescribeMove(uint64_t src_address, uint64_t dst_address, int32_t es, const int64_t extent[3],
+                                        const int64_t ss[3], const int64_t ds[3], int32_t flags, int64_t out[10]) {
+  try {
+    if (!extent || !ss || !ds || !out) CD_INVALID_USAGE("null argument");
+    if (es != 4 && es != 8 && es != 16) CD_INVALID_USAGE("element size must be 4, 8 or 16");
+    Move3D m;
+    for (int i = 0; i < 3; ++i) {
+      m.extent[i] = extent[i];
+      m.ss[i] = ss[i];
+      m.ds[i] = ds[i];
+    }
+    KernelTuning t;
+    if (flags & 2) t.force_streaming = true;
+    if (flags & 64) t.walk_order = 0;
+    if (flags & 128) t.walk_order = 1;
+    long long o[10];
+    describeMove(m, reinterpret_cast<const void*>(src_address), reinterpret_cast<void*>(dst_address), es, &t, o);
+    for (int i = 0; i < 10; ++i) out[i] = o[i];
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
 cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const int64_t extent[3],
                                    const int64_t ss[3], const int64_t ds[3], int32_t force_generic,
                                    int32_t* kernel_class, hipStream_t stream) {

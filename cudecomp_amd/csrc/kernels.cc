@@ -284,6 +284,19 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
 
 const char* lastKernelName() { return g_last_kernel; }
 
+void describeMove(const Move3D& m, const void* src, void* dst, int es, const KernelTuning* tuning, long long out[10]) {
+  Move3D mm = m;
+  mm.src_buf = BUF_IN;
+  mm.dst_buf = BUF_OUT;
+  mm.src_off = mm.dst_off = 0;
+  void* bufs[3] = {const_cast<void*>(src), dst, nullptr};
+  const Classified c = classify(mm, bufs, es, tuning, nullptr, false);
+  int ti = 0, tj = 0;
+  if (c.cls == MOVE_TRANSPOSE) tileOf(es, c.variant, c.window, &ti, &tj);
+  const long long v[10] = {(long long)c.cls, c.variant, ti, tj, c.t0, c.t1, c.dm.e[2], c.p0, c.p1, c.stream};
+  for (int i = 0; i < 10; ++i) out[i] = v[i];
+}
+
 void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStream_t stream,
                  const KernelTuning* tuning, KernelStats* stats, void* const* dst_base_override) {
   const bool remote = dst_base_override != nullptr;

@@ -38,6 +38,11 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
                  const KernelTuning* tuning = nullptr, KernelStats* stats = nullptr,
                  void* const* dst_base_override = nullptr);  // per-move destination base (remote buffers)
 
+// How a move WOULD run (no launch, no device needed): class, kernel variant, tile, tile counts, walk parameters, access mode.
+// out[10] = {class, variant, tile_i, tile_j, tiles_i, tiles_j, batch, p0 (run length), p1 (walk bits: 1 XCD-contiguous, 2 j first,
+// 4 runs over batch planes), access mode}.  (Tests of the planning logic: tests/test_kernel_plan.py.)
+void describeMove(const Move3D& m, const void* src, void* dst, int es, const KernelTuning* tuning, long long out[10]);
+
 // name (template spelling) of the data-movement kernel launched last by this process, "" before the first launch
 const char* lastKernelName();
 

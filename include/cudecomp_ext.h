@@ -215,12 +215,19 @@ cudecompResult_t cudecompExtEstimateCycleMs(cudecompHandle_t handle, const cudec
  * force_generic is a bit mask: 1 selects the element-wise fallback kernel, 2 forces the streaming
  * (non-temporal) variants that are normally used only for moves of 32 MiB and more, 4 selects the window variant of
  * the LDS transpose for every destination off the 64-byte grid (normally only for moves of 1 MiB and more), 8 disables
- * it; 16 / 32: 128 x 64 / 64 x 64 tiles for 4-byte transposes (tuning variants; the default is 64 x 128); 64: write-through stores, 128:
- * round-robin tile walk (diagnostic variants).  *kernel_class (optional) receives the
+ * it; 16 / 32: 128 x 64 / 64 x 64 tiles for 4-byte transposes (tuning variants; the default is 64 x 128); 64 / 128: transposes walk
+ * their tiles i first / j first (without runs).  *kernel_class (optional) receives the
  * kernel flavour used: 0 rows, 1 LDS transpose, 2 generic. */
 cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const int64_t extent[3],
                                    const int64_t ss[3], const int64_t ds[3], int32_t force_generic,
                                    int32_t* kernel_class, hipStream_t stream);
+
+/* How the kernel layer WOULD execute a 3-D block move between buffers at the given addresses (no launch; works without a
+ * GPU): out[10] = {class (0 rows, 1 LDS transpose, 2 generic), kernel variant, tile_i, tile_j, tiles_i, tiles_j, batch extent,
+ * run length of the tile walk, walk bits (1 XCD-contiguous, 2 j first, 4 runs over batch planes), access mode}.  flags: 2 =
+ * streaming access regardless of the size, 64 / 128 = force the i-first / j-first walk.  Harness-only (tests/test_kernel_plan.py). */
+cudecompResult_t cudecompExtDescribeMove(uint64_t src_address, uint64_t dst_address, int32_t es, const int64_t extent[3],
+                                        const int64_t ss[3], const int64_t ds[3], int32_t flags, int64_t out[10]);
 
 #ifdef __cplusplus
 }

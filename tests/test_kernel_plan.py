@@ -1,0 +1,115 @@
+"""Planning logic of the kernel layer on the CPU (no GPU, no launch): cudecompExtDescribeMove says how csrc/kernels.cc would
+run a move -- class, tile, tile walk, access mode.  The tile walk is re-stated here from the decode of
+csrc/kernels_tile.h (transpose_kernel) and must visit every tile exactly once for whatever run length the planner picks; the
+round-5 walks (runs of j tiles / of batch planes for far-strided destinations, taller tiles for far-strided sources) must be
+chosen for the bench shapes and only for large line-aligned moves."""
+import random
+
+import numpy as np
+
+import cudecomp_amd as cd
+
+SRC, DST = 1 << 32, 1 << 36  # line-aligned "addresses"
+
+
+def walk(d, blocks=None):
+    """(bi, bj, k) of every workgroup, as the kernel decodes them."""
+    ti_n, tj_n, batch, run, bits = d["tiles_i"], d["tiles_j"], d["batch"], d["run"], d["walk"]
+    nb = ti_n * tj_n * batch if blocks is None else blocks
+    out = np.empty((nb, 3), dtype=np.int64)
+    per = nb >> 3
+    for lb in range(nb):
+        lt = lb
+        if bits & 1 and lb < (per << 3):
+            lt = (lb & 7) * per + (lb >> 3)
+        if bits & 2:
+            if run > 1 and not bits & 4:
+                jlo, rest = lt % run, lt // run
+                bi, rest = rest % ti_n, rest // ti_n
+                runs = tj_n // run
+                bj, rest = (rest % runs) * run + jlo, rest // runs
+            elif run > 1:
+                bj, rest = lt % tj_n, lt // tj_n
+                klo, rest = rest % run, rest // run
+                bi, rest = rest % ti_n, (rest // ti_n) * run + klo
+            else:
+                bj, rest = lt % tj_n, lt // tj_n
+                bi, rest = rest % ti_n, rest // ti_n
+        else:
+            bi, rest = lt % ti_n, lt // ti_n
+            bj, rest = rest % tj_n, rest // tj_n
+        out[lb] = (bi, bj, rest)
+    return out
+
+
+def check_bijection(d):
+    w = walk(d)
+    assert (w[:, 0] < d["tiles_i"]).all() and (w[:, 1] < d["tiles_j"]).all() and (w[:, 2] < d["batch"]).all(), d
+    key = (w[:, 2] * d["tiles_j"] + w[:, 1]) * d["tiles_i"] + w[:, 0]
+    assert len(np.unique(key)) == len(key) == d["tiles_i"] * d["tiles_j"] * d["batch"], d
+
+
+def test_bench_shapes_take_the_round5_walks_and_tiles():
+    N = 1024
+    fwd = cd.cudecompExtDescribeMove(SRC, DST, 8, (N, N, N), (1, N, N * N), (N * N, 1, N))     # X->Y of the axis-contiguous cycle
+    bwd = cd.cudecompExtDescribeMove(SRC, DST, 8, (N, N, N), (1, N * N, N), (N, 1, N * N))     # Y->X
+    assert (fwd["cls"], fwd["tile_i"], fwd["tile_j"], fwd["access"]) == (1, 64, 64, 2)
+    assert fwd["walk"] & 2 and not fwd["walk"] & 4 and fwd["run"] * 64 * 8 == 256 << 10       # runs of 256 KiB per destination row
+    assert fwd["tiles_j"] % fwd["run"] == 0
+    assert (bwd["tile_i"], bwd["tile_j"], bwd["run"], bwd["access"]) == (64, 128, 0, 2)         # taller tiles, no runs
+    c128 = cd.cudecompExtDescribeMove(SRC, DST, 16, (N, N, 512), (1, N, N * N), (N * 512, 1, N))
+    assert (c128["tile_i"], c128["tile_j"]) == (32, 32) and c128["run"] * 32 * 16 == 256 << 10
+    c128b = cd.cudecompExtDescribeMove(SRC, DST, 16, (N, N, 512), (1, N * 512, N), (N, 1, N * N))
+    assert (c128b["tile_i"], c128b["tile_j"], c128b["run"]) == (32, 64, 0)
+    f32 = cd.cudecompExtDescribeMove(SRC, DST, 4, (2048, N, N), (1, 2048, 2048 * N), (N * N, 1, N))
+    assert (f32["tile_i"], f32["tile_j"]) == (64, 128) and f32["run"] * 128 * 4 == 256 << 10
+    # forcing a walk (tuning switch) switches the runs off; small moves (cached access) never take them
+    assert cd.cudecompExtDescribeMove(SRC, DST, 8, (N, N, N), (1, N, N * N), (N * N, 1, N), flags=128)["run"] == 0
+    small = cd.cudecompExtDescribeMove(SRC, DST, 8, (128, 128, 64), (1, 128, 128 * 128), (128 * 64, 1, 128))
+    assert small["access"] == 0 and small["run"] == 0 and small["tile_j"] == 64
+    # misaligned destinations go to the window kernel / cached stores, never to the run walk
+    mis = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (N, N, N), (1, N, N * N), (N * N + 2, 1, N + 2), flags=0)
+    assert mis["run"] == 0
+
+
+def test_every_walk_visits_every_tile_once():
+    rng = random.Random(5)
+    seen_runs = {"j": 0, "k": 0, "none": 0}
+    for _ in range(300):
+        es = rng.choice([4, 8, 16])
+        fused = rng.random() < 0.5
+        ei = rng.choice([64, 128, 192, 320, 1000])
+        ej = rng.choice([64, 128, 256, 384, 1000])
+        ek = rng.choice([4, 8, 12, 30, 32, 36, 48, 64])
+        if fused:   # destination (j, k, i) dense: the planner fuses j and k into one long dim
+            ss, ds = (1, ei, ei * ej), (ej * ek, 1, ej)
+        else:       # padded planes in the destination keep k a dim of its own
+            ss, ds = (1, ei, ei * ej), ((ej + 16) * ek, 1, ej + 16)
+        d = cd.cudecompExtDescribeMove(SRC, DST, es, (ei, ej, ek), ss, ds, flags=2)  # streaming access regardless of the size
+        if d["cls"] != 1:
+            continue
+        if d["run"] > 1:
+            if d["walk"] & 4:
+                assert d["batch"] % d["run"] == 0, d
+                seen_runs["k"] += 1
+            else:
+                assert d["tiles_j"] % d["run"] == 0, d
+                seen_runs["j"] += 1
+        else:
+            seen_runs["none"] += 1
+        if d["tiles_i"] * d["tiles_j"] * d["batch"] <= 40000:
+            check_bijection(d)
+    assert seen_runs["k"] > 10 and seen_runs["none"] > 10, seen_runs
+    # long fused destination rows: runs of j tiles (a divisor of the tile count near 256 KiB / tile width)
+    for es, ei, ej, ek in [(8, 128, 1024, 64), (8, 64, 2048, 48), (16, 64, 1024, 40), (4, 128, 4096, 40), (8, 192, 1000, 72), (8, 64, 1536, 50)]:
+        d = cd.cudecompExtDescribeMove(SRC, DST, es, (ei, ej, ek), (1, ei, ei * ej), (ej * ek, 1, ej), flags=2)
+        assert d["cls"] == 1 and d["batch"] == 1, d          # (j, k) fused
+        assert d["run"] > 1 and not d["walk"] & 4 and d["tiles_j"] % d["run"] == 0, d
+        assert 64 << 10 <= d["run"] * d["tile_j"] * es <= 256 << 10, d
+        check_bijection(d)
+
+
+def test_run_walks_by_hand():
+    for ti_n, tj_n, batch, run, bits in [(3, 8, 2, 4, 3), (5, 12, 1, 6, 3), (2, 3, 8, 4, 7), (4, 5, 6, 2, 7), (3, 7, 5, 0, 3), (3, 7, 5, 0, 1),
+                                         (16, 64, 1, 8, 2)]:
+        check_bijection({"tiles_i": ti_n, "tiles_j": tj_n, "batch": batch, "run": run, "walk": bits})
