@@ -40,6 +40,7 @@ from tests.test_gpu_runner_cases import load_cases  # noqa: E402
 
 SHIM = os.path.join(ROOT, "tests", "shim", "libfake_rccl.so")
 MAX_CASES = 150000
+KEEP = [None]  # directory for the results and the excerpts (small); the bulky per-rank logs go to a scratch directory
 
 
 def case_file(lines, n, seed):
@@ -122,17 +123,33 @@ def run(outdir, name, binary, nranks, lines, env_extra, seconds):
            "ms_per_case": round(1000 * wall / max(1, passed + failed), 2), "kfd_queues_max": census, "failing": failing[:20],
            "diag": diag[:60], "gate_reports": gate[:8], "exit_codes": [p.returncode for p in procs]}
     print(json.dumps(rec), flush=True)
-    # keep the per-rank logs only when they say something
-    if not (failed or stale or rec["download_mismatches"] or rec["interior_overwritten"]):
-        for r in range(1, nranks):
-            os.unlink(os.path.join(outdir, "%s_rank%d.log" % (name, r)))
-        os.unlink(path)
+    # The per-rank logs are bulky (a line or two per case: 15-20 MB per program run) and gpurun copies back at most 64 MiB:
+    # they live in a scratch directory; what says something (DIAG lines, failing cases with their neighbourhood, the gate's
+    # report) is written as a small excerpt next to the results.
+    if failed or stale or rec["download_mismatches"] or rec["interior_overwritten"]:
+        with open(os.path.join(KEEP[0], name + "_excerpt.log"), "w") as f:
+            for r in range(nranks):
+                lines_r = open(os.path.join(outdir, "%s_rank%d.log" % (name, r)), errors="replace").read().splitlines()
+                f.write("===== rank %d (%d lines)\n" % (r, len(lines_r)))
+                want = set()
+                for i, line in enumerate(lines_r):
+                    if line.startswith("DIAG") or "cells differ" in line or "CUDECOMP:" in line or line.strip() == "FAILED" or line.startswith("Input gate"):
+                        want.update(range(max(0, i - 3), min(len(lines_r), i + 2)))
+                for i in sorted(want)[:400]:
+                    f.write(lines_r[i][:1000] + "\n")
+    for r in range(nranks):
+        os.unlink(os.path.join(outdir, "%s_rank%d.log" % (name, r)))
+    os.unlink(path)
     return rec
 
 
 def main():
-    outdir, per_arm = sys.argv[1], float(sys.argv[2])
+    keepdir, per_arm = sys.argv[1], float(sys.argv[2])
     opts = sys.argv[3:]
+    import tempfile
+    os.makedirs(keepdir, exist_ok=True)
+    KEEP[0] = keepdir
+    outdir = tempfile.mkdtemp(prefix="upload_ab_")
 
     def opt(name, dflt):
         return opts[opts.index(name) + 1] if name in opts else dflt
@@ -140,7 +157,6 @@ def main():
     libdir = opt("--lib", os.path.join(ROOT, "cudecomp_amd", "lib_tuning"))
     nranks = int(opt("--ranks", "8"))
     arms = opt("--arms", "default,pinned,sync").split(",")
-    os.makedirs(outdir, exist_ok=True)
     cases = load_cases(8 if nranks == 8 else 4)
     halo, trans = cases["halo_test_mix_cc"], cases["transpose_test_mix_cc"]
     size = subprocess.run("readelf -S -W %s/libcudecomp.so | grep ' .hip_fatbin '" % libdir, shell=True, capture_output=True, text=True).stdout.split()
