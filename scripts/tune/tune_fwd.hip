@@ -263,6 +263,18 @@ int main(int argc, char** argv) {
       ROW(8, 2, 32, 64, 2, true, "jik", 1, 1)
       ROW(8, 2, 64, 32, 2, true, "jik", 1, 1)
     }
+  } else if (es == 8 && phase == 4) {  // the run walk with other tiles / access modes (the mode A/B of phase 1 used plain j first)
+    for (int rep = 0; rep < 2; ++rep) {
+      ROW(8, 2, 64, 64, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 64, 64, 4, true, "jlih", 32, 1)
+      ROW(8, 2, 64, 64, 1, true, "jlih", 32, 1)
+      ROW(8, 2, 64, 64, 0, true, "jlih", 32, 1)
+      ROW(8, 2, 64, 32, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 32, 64, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 32, 32, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 128, 64, 2, true, "jlih", 32, 1)
+      ROW(8, 2, 64, 64, 2, false, "jlih", 32, 1)
+    }
   } else if (es == 8 && phase == 3) {
     for (int rep = 0; rep < 2; ++rep) {
       ROW(8, 2, 64, 64, 2, true, "jik", 1, 1)
