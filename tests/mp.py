@@ -195,5 +195,18 @@ def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
         if p.returncode != 0:
             failures.append("rank %d exit %s\n%s" % (r, p.returncode, text[-4000:]))
     if failures:
+        # keep what every rank said where gpurun merges it back: the lines that matter (DIAG, failing commands) are rarely in the tail
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "ranks_failure_%s_%d.log" % (os.path.basename(str(argv[0])), os.getpid())), "w") as f:
+                for r, text in enumerate(logs):
+                    keep, lines_r = set(), text.splitlines()
+                    for i, line in enumerate(lines_r):
+                        if line.startswith("DIAG") or "differ" in line or "CUDECOMP:" in line or line.strip() == "FAILED" or "Input gate" in line:
+                            keep.update(range(max(0, i - 2), min(len(lines_r), i + 2)))
+                    f.write("===== rank %d (%d lines)\n" % (r, len(lines_r)))
+                    f.write("\n".join(lines_r[i][:1200] for i in sorted(keep)[:300]) + "\n")
+        except OSError:
+            pass
         raise AssertionError("\n".join(failures))
     return logs

@@ -61,7 +61,7 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
     T_CHECK_CD(cudecompGetPencilInfo(handle, gdesc, &p, axis, halo.data(), pad.data()));
     int64_t ws = 0;
     T_CHECK_CD(cudecompGetHaloWorkspaceSize(handle, gdesc, axis, halo.data(), &ws));
-    T_CHECK_HIP(hipMalloc((void**)&data, p.size * sizeof(elem_t)));
+    data = TestBuffer::get(0, p.size);
     T_CHECK_CD(cudecompMalloc(handle, gdesc, (void**)&work, std::max<int64_t>(ws, 1) * sizeof(elem_t)));
 
     std::vector<elem_t> init, ref, host(p.size);
@@ -97,12 +97,12 @@ static int runCase(cudecompHandle_t handle, const Options& o, bool silent) {
       diagnoseMismatch("halo", data, host, ref, &init, p, false);
     }
   } catch (...) {
-    if (data) (void)hipFree(data);
+    if (data && !TestBuffer::reuse()) (void)hipFree(data);
     if (work) (void)cudecompFree(handle, gdesc, work);
     (void)cudecompGridDescDestroy(handle, gdesc);
     throw;
   }
-  T_CHECK_HIP(hipFree(data));
+  TestBuffer::put(data);
   T_CHECK_CD(cudecompFree(handle, gdesc, work));
   notePaths(handle, gdesc);
   T_CHECK_CD(cudecompGridDescDestroy(handle, gdesc));

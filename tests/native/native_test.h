@@ -426,6 +426,17 @@ __global__ void gate_sum_k(const unsigned int* __restrict__ w, long long nwords,
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
+// the same sum by the workgroups of ONE XCD only (workgroup b runs on XCD b % 8): which XCD's view of the buffer is stale?
+__global__ void gate_sum_xcd_k(const unsigned int* __restrict__ w, long long nwords, unsigned long long* out, int xcd) {
+  if ((int)(blockIdx.x % 8) != xcd) return;
+  const long long nb = gridDim.x / 8, b = blockIdx.x / 8;
+  unsigned long long acc = 0;
+  for (long long i = b * blockDim.x + threadIdx.x; i < nwords; i += nb * blockDim.x)
+    acc += (unsigned long long)(w[i] ^ (unsigned int)((unsigned long long)i * 2654435761ull)) * (unsigned long long)(2 * i + 1);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 struct InputGate {
   long long checks = 0, stale_inputs = 0, stale_downloads = 0, interior_overwritten = 0;
   unsigned long long* d_sum = nullptr;
@@ -470,6 +481,15 @@ struct InputGate {
     T_CHECK_HIP(hipDeviceSynchronize());
     std::this_thread::sleep_for(std::chrono::milliseconds(1));
     const unsigned long long again = deviceSum(dev, bytes, stream);
+    // which XCD disagrees?  the same sum computed by the workgroups of one XCD at a time
+    char per_xcd[8 * 12 + 1] = "";
+    for (int x = 0; x < 8; ++x) {
+      T_CHECK_HIP(hipMemsetAsync(d_sum, 0, 8, stream));
+      gate_sum_xcd_k<<<8 * 32, 256, 0, stream>>>(static_cast<const unsigned int*>(static_cast<const void*>(dev)), (long long)(bytes / 4), d_sum, x);
+      T_CHECK_HIP(hipMemcpyAsync(h_sum, d_sum, 8, hipMemcpyDeviceToHost, stream));
+      T_CHECK_HIP(hipStreamSynchronize(stream));
+      std::snprintf(per_xcd + std::strlen(per_xcd), 12, " %s", *h_sum == want ? "ok" : "STALE");
+    }
     std::vector<elem_t> back((size_t)nel);
     T_CHECK_HIP(hipMemcpy(back.data(), dev, bytes, hipMemcpyDeviceToHost));
     int64_t bad = 0, lo = -1, hi = -1;
@@ -481,9 +501,9 @@ struct InputGate {
       }
     fprintf(stderr,
             "DIAG rank %d %s: input stale before call: kernel checksum %016llx, host %016llx; second kernel look after a device sync "
-            "%s; read back with hipMemcpy: %lld of %lld cells differ from the upload, in [%lld, %lld] (dev %p)\n",
-            worldRank(), what, got, want, again == want ? "RIGHT (the upload landed late)" : "still wrong", (long long)bad,
-            (long long)nel, (long long)lo, (long long)hi, (const void*)dev);
+            "%s (%016llx); per XCD 0..7:%s; read back with hipMemcpy: %lld of %lld cells differ from the upload, in [%lld, %lld] (dev %p)\n",
+            worldRank(), what, got, want, again == want ? "RIGHT (the upload landed late)" : (again == got ? "the SAME wrong sum" : "another wrong sum"),
+            again, per_xcd, (long long)bad, (long long)nel, (long long)lo, (long long)hi, (const void*)dev);
     return true;
   }
   // AFTER the call (device idle): does the host copy the verdict is computed from agree with what a kernel sees?
@@ -504,11 +524,16 @@ struct InputGate {
   }
 };
 
-// Data buffers of the test programs: hipMalloc / hipFree per case as the reference's programs do, or -- with
-// CUDECOMP_TEST_REUSE_BUFFERS=1 (an arm of the hunt: does allocation churn matter?) -- grown once and kept for the process.
+// Data buffers of the test programs: grown once and kept for the process (default), or -- CUDECOMP_TEST_REUSE_BUFFERS=0 --
+// hipMalloc / hipFree per case as the reference's programs do.  Why the default deviates from the reference: with eight
+// processes SHARING one GPU, a buffer that was freed and re-allocated per case is sometimes seen STALE by exactly one XCD --
+// the input-integrity gate below caught it before any library call: the per-XCD checksums of a freshly uploaded pencil read
+// "ok ok ok ok ok ok STALE ok", the same wrong sum after a device synchronisation, while hipMemcpy reads the right data back
+// (profiles/r05_stale_xcd_view.md).  The reference's 8-rank transpose_test_cc list (R64) failed in 7 of 7
+// runs with per-case allocation and in 0 of 3 with kept buffers, with this round's library and with round 4's alike.
 struct TestBuffer {
   static bool reuse() {
-    static const bool r = [] { const char* v = std::getenv("CUDECOMP_TEST_REUSE_BUFFERS"); return v && std::atoi(v) != 0; }();
+    static const bool r = [] { const char* v = std::getenv("CUDECOMP_TEST_REUSE_BUFFERS"); return !v || std::atoi(v) != 0; }();
     return r;
   }
   static elem_t* get(int slot, int64_t nel) {
