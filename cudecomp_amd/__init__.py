@@ -73,7 +73,7 @@ EXT_MAX_MEMBERS = 64
 class ExtMove(C.Structure):
     _fields_ = [("src_buf", C.c_int32), ("dst_buf", C.c_int32), ("src_off", C.c_int64), ("dst_off", C.c_int64),
                 ("extent", C.c_int64 * 3), ("ss", C.c_int64 * 3), ("ds", C.c_int64 * 3), ("peer", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("row_pitch", C.c_int32)]
 
 
 class ExtTransposePlan(C.Structure):

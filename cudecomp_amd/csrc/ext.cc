@@ -18,6 +18,15 @@ cudecompResult_t fail(const Error& e) {
   return e.code();
 }
 
+// tests: "the cells between consecutive destination rows are the move's to rewrite" -- the pitch of consecutive rows is the
+// smallest destination stride among the dims that are not the unit-stride one
+i64 wholeRowsPitchOf(const Move3D& m) {
+  i64 pitch = 0;
+  for (int i = 0; i < 3; ++i)
+    if (m.extent[i] > 1 && m.ds[i] > 1 && (pitch == 0 || m.ds[i] < pitch)) pitch = m.ds[i];
+  return pitch;
+}
+
 void exportMove(const Move3D& m, cudecompExtMove_t* o) {
   o->src_buf = m.src_buf;
   o->dst_buf = m.dst_buf;
@@ -29,7 +38,7 @@ void exportMove(const Move3D& m, cudecompExtMove_t* o) {
     o->ds[i] = m.ds[i];
   }
   o->peer = m.peer;
-  o->reserved = 0;
+  o->row_pitch = (int32_t)std::min<i64>(m.dst_row_pitch, 0x7fffffff);
 }
 
 void exportTransposePlan(const TransposePlan& p, const std::vector<int>& global_ranks, cudecompExtTransposePlan_t* out) {
@@ -521,8 +530,10 @@ cudecompResult_t cudecompExtDescribeMove(uint64_t src_address, uint64_t dst_addr
       m.ss[i] = ss[i];
       m.ds[i] = ds[i];
     }
+    if (flags & 256) m.dst_row_pitch = wholeRowsPitchOf(m);
     KernelTuning t;
     if (flags & 2) t.force_streaming = true;
+    if (flags & 4) t.window_mode = 1;
     if (flags & 64) t.walk_order = 0;
     if (flags & 128) t.walk_order = 1;
     long long o[10];
@@ -550,6 +561,7 @@ cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const
       m.ss[i] = ss[i];
       m.ds[i] = ds[i];
     }
+    if (force_generic & 256) m.dst_row_pitch = wholeRowsPitchOf(m);  // the cells between consecutive destination rows are the move's to rewrite
     void* bufs[3] = {const_cast<void*>(src), dst, nullptr};
     KernelTuning t;
     if (force_generic & 1) t.force_class = MOVE_GENERIC;

@@ -32,11 +32,14 @@ struct Classified {
   int p0, p1;
   int stream;  // 0 default caching, 1 streaming loads, 2 streaming loads + stores, 3 streaming loads + remote stores
   bool swizzle = false;  // transposes: XOR-swizzled LDS tile (else padded rows)
-  bool window = false;   // transposes: destination rows off the 64-byte grid -> transpose_window_kernel
+  bool window = false;   // transposes: destination rows off the 64-byte grid -> transpose_window_kernel (rows: rows_shifted_kernel)
+  bool dense = false;    // rows, with window: whole lines across the row ends (rows_dense_kernel)
   unsigned int t0, t1;
   unsigned long long blocks;
   i64 elements;
 };
+
+constexpr long long kDenseMaxGapBytes = 512;  // widest gap between rows the dense row copy rewrites (halo + padding cells)
 
 int ilog2ceil(long long x) {
   int l = 0;
@@ -78,6 +81,38 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
       c.window = true;
       c.p1 = (int)(m.extent[0] * es);  // row length in bytes (rows longer than 2 GiB keep the plain kernel)
       if (m.extent[0] * es > 0x7fffffffLL) c.window = false;
+    }
+    // ... and when the move covers whole interior rows of a halo-carrying pencil (the planner says so and names the pencil's
+    // row pitch: dst_row_pitch) and the gap between consecutive rows is a few halo / padding cells: the dense walk of
+    // rows_dense_kernel, which writes whole lines across the row ends.  Local destinations only; dim 1 must be the one that
+    // steps by the pencil's row pitch (a move one row tall per plane has no such dim: its rows are whole planes apart, with
+    // other moves' rows in between).  A row that normalizeMove has fused with the next dim -- no gap -- keeps the shifted kernel.
+    i64 planned_row = -1;
+    for (int i = 0; i < 3; ++i)
+      if (in.ss[i] == 1 && in.ds[i] == 1 && in.extent[i] > 1) planned_row = in.extent[i];
+    if (c.window && in.dst_row_pitch > 0 && !remote && planned_row == m.extent[0] && c.dm.e[1] > 1 &&
+        (!tuning || tuning->dense_rows != 0)) {
+      DevMove d = c.dm;
+      if (d.e[2] > 1 && d.ds[2] < d.ds[1]) {
+        std::swap(d.e[1], d.e[2]);
+        std::swap(d.ss[1], d.ss[2]);
+        std::swap(d.ds[1], d.ds[2]);
+      }
+      const long long row_bytes = m.extent[0] * es, gap = d.ds[1] - row_bytes;
+      const long long span = (d.e[1] - 1) * d.ds[1] + row_bytes;
+      const bool planes_apart = d.e[2] == 1 || span <= d.ds[2];
+      if (d.e[1] > 1 && d.ds[1] == in.dst_row_pitch * es && gap > 0 && gap <= kDenseMaxGapBytes && gap * 8 <= row_bytes && planes_apart) {
+        c.dense = true;
+        c.variant = 16;
+        c.dm = d;
+        c.dm.e[0] = row_bytes;
+        c.p0 = 0;
+        const long long per = rowsDenseBytesPerBlock();
+        c.t0 = (unsigned int)((span + 63 + per - 1) / per);  // (+63: the lanes start at the 64-byte boundary below the first row)
+        c.t1 = 1;
+        c.blocks = (unsigned long long)c.t0 * (unsigned long long)c.dm.e[2];
+        return c;
+      }
     }
     if (c.window) c.dm.e[0] += 64 / vb;  // one unit of slack vectors per row (see rows_shifted_kernel)
     c.p0 = std::min(8, ilog2ceil(c.dm.e[0]));
@@ -248,14 +283,14 @@ void tileOf(int es, int variant, bool window, int* ti, int* tj) {
   }
 }
 
-void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bool window, int es, const Batch& b,
+void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bool window, bool dense, int es, const Batch& b,
                  unsigned int blocks, hipStream_t stream) {
   // what ran last, in the words of the kernel templates (bench.py reports its dominant kernel from here)
   int ti = 0, tj = 0;
   tileOf(es, variant, window, &ti, &tj);
   if (cls == MOVE_ROWS_VEC)
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d>", window ? "rows_shifted_kernel" : "rows_kernel", variant,
-             stream_access == 3 ? 3 : (stream_access >= 1 ? 1 : 0));
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d>", dense ? "rows_dense_kernel" : (window ? "rows_shifted_kernel" : "rows_kernel"),
+             variant, stream_access == 3 ? 3 : (stream_access >= 1 ? 1 : 0));
   else if (cls == MOVE_TRANSPOSE && window)
     snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_window_kernel<%d,%d,%d,%d,%d>", es, variant % 100, ti, tj,
              (stream_access == 2 || stream_access == 4) ? 4 : stream_access);
@@ -266,7 +301,7 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
     snprintf(g_last_kernel, sizeof(g_last_kernel), "generic_kernel<%d,%s>", es, stream_access == 3 ? "true" : "false");
   switch (cls) {
     case MOVE_ROWS_VEC:
-      launchRowsBatch(window, variant, stream_access, b, blocks, stream);
+      launchRowsBatch(dense ? 2 : (window ? 1 : 0), variant, stream_access, b, blocks, stream);
       break;
     case MOVE_TRANSPOSE:
       if (window) launchWindowBatch(es, variant % 100, variant >= 100, stream_access, b, blocks, stream);
@@ -285,7 +320,7 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
 const char* lastKernelName() { return g_last_kernel; }
 
 void describeMove(const Move3D& m, const void* src, void* dst, int es, const KernelTuning* tuning, long long out[10]) {
-  Move3D mm = m;
+  Move3D mm = m;  // (keeps dst_row_pitch)
   mm.src_buf = BUF_IN;
   mm.dst_buf = BUF_OUT;
   mm.src_off = mm.dst_off = 0;
@@ -293,6 +328,7 @@ void describeMove(const Move3D& m, const void* src, void* dst, int es, const Ker
   const Classified c = classify(mm, bufs, es, tuning, nullptr, false);
   int ti = 0, tj = 0;
   if (c.cls == MOVE_TRANSPOSE) tileOf(es, c.variant, c.window, &ti, &tj);
+  else if (c.cls == MOVE_ROWS_VEC) ti = c.dense ? 2 : (c.window ? 1 : 0);  // rows: the kernel (plain / shifted / dense) in the tile_i slot
   const long long v[10] = {(long long)c.cls, c.variant, ti, tj, c.t0, c.t1, c.dm.e[2], c.p0, c.p1, c.stream};
   for (int i = 0; i < 10; ++i) out[i] = v[i];
 }
@@ -315,7 +351,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
     unsigned long long blocks = 0;
     for (size_t j = i; j < cs.size() && b.n < kMaxBatch; ++j) {
       if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant || cs[j].stream != cs[i].stream ||
-          cs[j].swizzle != cs[i].swizzle || cs[j].window != cs[i].window)
+          cs[j].swizzle != cs[i].swizzle || cs[j].window != cs[i].window || cs[j].dense != cs[i].dense)
         continue;
       if (blocks + cs[j].blocks > 0x7fffffffULL) {
         if (b.n == 0) CD_NOT_SUPPORTED("single block move too large for one launch");
@@ -346,7 +382,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
         blocks = widest * b.n;
       }
     }
-    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, cs[i].swizzle, cs[i].window, es, b, (unsigned int)blocks, stream);
+    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, cs[i].swizzle, cs[i].window, cs[i].dense, es, b, (unsigned int)blocks, stream);
     if (stats) stats->launches[cs[i].cls] += 1;
   }
 }

@@ -45,7 +45,9 @@ struct Batch {
 // ---- launchers, one per code object (host side; csrc/kernels.cc decides what runs) -------------------------------------------
 // stream_access: 0 default caching, 1 non-temporal loads, 2 non-temporal loads + stores, 3 non-temporal loads + remote
 // (system-scope write-through) stores, 4 cached loads + non-temporal stores (see storePolicyOf)
-void launchRowsBatch(bool shifted, int vector_bytes, int stream_access, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
+// rows: mode 0 plain, 1 shifted (lanes on the destination's 64-byte grid), 2 dense (whole lines across row ends, Move3D::dst_rows_whole)
+void launchRowsBatch(int mode, int vector_bytes, int stream_access, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
+int rowsDenseBytesPerBlock();  // bytes of a plane's span one workgroup of the dense row copy covers
 void launchGenericBatch(int es, bool remote, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
 // transposes: `variant` = elements per 16-byte lane group (1 = element-wise lanes), plus 300 for the 64 x 128 tile of 4-byte
 // elements (tuning builds: 200 = 128 x 64, 0 = 64 x 64)

@@ -7,6 +7,8 @@
 //                         keeps 4 vectors per lane (16 KiB) in flight, lanes run along the row so that every wavefront touches
 //                         1 KiB contiguous segments.  No per-element index math: one (row, plane) decode per WORKGROUP.
 //   rows_shifted_kernel   the same for destination rows off the 64-byte grid.
+//   rows_dense_kernel     the same when, in addition, the cells between consecutive destination rows belong to the move
+//                         (whole interior rows of a halo-carrying pencil): whole cache lines across the row ends.
 //   generic_kernel<ES>    degenerate shapes (no unit stride on one side, 1-element rows).
 // Pure data movement: no MFMA; the bound is HBM (8 TB/s spec, ~6.3 TB/s achievable copy rate).
 #include "kernels_dev.h"
@@ -140,6 +142,97 @@ __global__ __launch_bounds__(kThreads) void rows_shifted_kernel(const Batch b) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// rows_dense_kernel: row copy onto a halo-carrying pencil whose rows the move covers WHOLE (Move3D::dst_rows_whole).
+// What costs on such destinations is not the misalignment but every 128-byte line that is only partly written -- the two
+// lines at the ends of each row, about four line times each (profiles/r05_tuning.md section 3: 8 GiB onto rows of 8192 B at a
+// pitch of 8208 B 3.25 ms against 2.85 ms aligned).  Here the lanes walk the destination's LINEAR address space on the 64-byte
+// grid, across the row boundaries of a plane: every store of the body is a whole aligned 16-byte vector, every wavefront
+// instruction writes 1 KiB of whole lines.  The few bytes between the end of one row and the start of the next (halo /
+// padding cells of the same pencil, nobody else's during the operation) are read from the destination and written back
+// unchanged.  Nothing is read or written below the first byte of a plane's first row or above the last byte of its last row:
+// the two ends of a plane's span are copied in masked 4-byte pieces.  (Probe: scripts/tune/partial_probe.hip "dense": 2.83-2.87 ms.)
+// e[0] = row length in BYTES, e[1] = rows per plane, e[2] = planes; ss/ds[1], [2] in bytes, ds[1] <= ds[2]; t0 = workgroups per
+// plane; a workgroup covers kDenseBytes of the span.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDenseBytes = kThreads * 16 * kRowsUnroll;
+
+template <int STREAM>
+__global__ __launch_bounds__(kThreads) void rows_dense_kernel(const Batch b) {
+  using V = Bytes<16>;
+  constexpr int POLICY = STREAM >= 1 ? ST_STREAM : ST_CACHED;
+  int mi;
+  unsigned int lb;
+  if (!locate(b, blockIdx.x, mi, lb)) return;
+  const DevMove& m = b.m[mi];
+  const unsigned int per_plane = b.t0[mi];
+  const long long plane = lb / per_plane;
+  const long long chunk = lb % per_plane;
+  const long long row_bytes = m.e[0], pitch = m.ds[1], spitch = m.ss[1];
+  const char* __restrict__ s = m.src + plane * m.ss[2];
+  char* __restrict__ d0 = m.dst + plane * m.ds[2];  // first byte of the plane's first row
+  const long long shift = (long long)(reinterpret_cast<uintptr_t>(d0) & 63);
+  const long long span = (m.e[1] - 1) * pitch + row_bytes;  // first byte of the first row .. last byte of the last row
+  const double inv_pitch = 1.0 / (double)pitch;
+
+  V v[kRowsUnroll];
+  long long pos[kRowsUnroll];
+  int kind[kRowsUnroll];  // 0 nothing, 1 whole vector, 2 an end of the span (masked pieces)
+#pragma unroll
+  for (int u = 0; u < kRowsUnroll; ++u) {
+    const long long p = ((chunk * kRowsUnroll + u) * kThreads + threadIdx.x) * 16 - shift;  // byte offset from d0, 16-byte aligned address
+    pos[u] = p;
+    kind[u] = 0;
+    if (p >= span || p + 16 <= 0) continue;
+    // row and offset inside the row's pitch of byte max(p, 0): quotient by reciprocal, off by one at most
+    const long long pc = p < 0 ? 0 : p;
+    long long r = (long long)((double)pc * inv_pitch);
+    long long o = pc - r * pitch;
+    if (o < 0) {
+      --r;
+      o += pitch;
+    } else if (o >= pitch) {
+      ++r;
+      o -= pitch;
+    }
+    if (p >= 0 && o + 16 <= row_bytes) {  // inside one row: the body
+      kind[u] = 1;
+      v[u] = loadVec<(STREAM >= 1), 16>(s + r * spitch + o);
+      continue;
+    }
+    // a vector that holds a row end, a piece of the gap or an end of the span: dword by dword -- from the source inside a
+    // row, from the destination itself inside a gap
+    kind[u] = (p >= 0 && p + 16 <= span) ? 1 : 2;
+    o -= pc - p;  // offset of byte p (negative only in front of the first row)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long pp = p + 4 * k;
+      unsigned int w = 0;
+      if (pp >= 0 && pp < span) {
+        long long rr = r, oo = o + 4 * k;
+        if (oo >= pitch) {
+          ++rr;
+          oo -= pitch;
+        }
+        w = oo < row_bytes ? *reinterpret_cast<const unsigned int*>(s + rr * spitch + oo) : *reinterpret_cast<const unsigned int*>(d0 + pp);
+      }
+      v[u][k] = w;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kRowsUnroll; ++u) {
+    if (kind[u] == 1) {
+      storeVec<POLICY, 16>(d0 + pos[u], v[u]);
+    } else if (kind[u] == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long long pp = pos[u] + 4 * k;
+        if (pp >= 0 && pp < span) storeVec<POLICY, 4>(d0 + pp, v[u][k]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic_kernel: element-wise, lanes along dim p0 (the destination-fast dim when there is one).
 // ---------------------------------------------------------------------------------------------
 template <int ES, bool REMOTE>
@@ -170,9 +263,18 @@ __global__ __launch_bounds__(kThreads) void generic_kernel(const Batch b) {
 
 using namespace kern;
 
-void launchRowsBatch(bool shifted, int vb, int stream_access, const Batch& b, unsigned int blocks, hipStream_t stream) {
+int rowsDenseBytesPerBlock() { return kern::kDenseBytes; }
+
+void launchRowsBatch(int mode, int vb, int stream_access, const Batch& b, unsigned int blocks, hipStream_t stream) {
   const dim3 grid(blocks), block(kThreads);
   const int rs = stream_access == 3 ? 3 : (stream_access >= 1 ? 1 : 0);  // (4 only occurs for transposes)
+  const bool shifted = mode == 1;
+  if (mode == 2) {  // local destinations only (kernels.cc classify())
+    if (rs == 1) rows_dense_kernel<1><<<grid, block, 0, stream>>>(b);
+    else rows_dense_kernel<0><<<grid, block, 0, stream>>>(b);
+    CD_CHECK_HIP(hipGetLastError());
+    return;
+  }
 #define CD_ROWS(K, VB)                                                    \
   do {                                                                    \
     if (rs == 3) K<VB, 3><<<grid, block, 0, stream>>>(b);                 \

@@ -98,6 +98,7 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
     // do if the layouts agree, else stage the interior through the workspace.
     if (!inplace) {
       p.pack.push_back(blockMove(BUF_IN, ah.interiorOffset(), ast, BUF_OUT, bh.interiorOffset(), bst, Sa, 0));
+      p.pack.back().dst_row_pitch = Sb[b.order[0]] > 1 ? bst[b.order[1]] : 0;  // the whole interior of the output pencil
     } else if (orders_equal && hp_equal) {
       p.noop = true;
     } else {
@@ -105,6 +106,7 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
       denseStrides(b.order, Sb, wst);
       p.pack.push_back(blockMove(BUF_IN, ah.interiorOffset(), ast, BUF_WORK, 0, wst, Sa, 0));
       p.unpack.push_back(blockMove(BUF_WORK, 0, wst, BUF_OUT, bh.interiorOffset(), bst, Sb, 0));
+      p.unpack.back().dst_row_pitch = Sb[b.order[0]] > 1 ? bst[b.order[1]] : 0;
     }
     p.schedule_dst = {0};
     p.schedule_src = {0};
@@ -200,6 +202,9 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
       denseStrides(W, E, wst);
       p.unpack.push_back(blockMove(BUF_WORK, p.recv_base + p.recv_off[s], wst, BUF_OUT,
                                    bh.interiorOffset() + off_b[s] * bst[ax.b], bst, E, s));
+      // the chunks are slabs along ax_b: unless that is the output's fastest memory axis every chunk holds whole rows
+      // (one-element rows excepted: the next axis is then the contiguous one, and it may be the split one)
+      p.unpack.back().dst_row_pitch = ((b.order[0] != ax.b) && Sb[b.order[0]] > 1) ? bst[b.order[1]] : 0;
     }
   }
   return p;
@@ -216,6 +221,7 @@ Move3D stageOfMove(const Move3D& m, int axis, int k, int K) {
   r.extent[axis] = hi - lo;
   r.src_off += lo * m.ss[axis];
   r.dst_off += lo * m.ds[axis];
+  if (K > 1 && m.ds[axis] == 1) r.dst_row_pitch = 0;  // (a stage that cuts the rows themselves)
   return r;
 }
 

@@ -27,6 +27,13 @@ struct Move3D {
   i64 ss[3] = {0, 0, 0};
   i64 ds[3] = {0, 0, 0};
   int peer = -1;  // communicator rank this move feeds / drains (-1: not tied to one peer)
+  // > 0: the move writes WHOLE interior rows of the destination pencil (its unit-stride dim spans the pencil's interior
+  // along the fastest memory axis) and this is the pencil's row pitch in elements.  The cells between the end of one row and
+  // the start of the row one pitch further are then halo / padding cells of that pencil, written by nobody during the
+  // operation, and the kernel layer may write whole cache lines across the row ends, putting back into those cells what it
+  // read from them (rows_dense_kernel, kernels_rows.hip).  Only ever set for local destinations (never for puts into a
+  // peer's pencil).
+  i64 dst_row_pitch = 0;
 
   i64 elements() const { return extent[0] * extent[1] * extent[2]; }
 };

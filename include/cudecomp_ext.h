@@ -24,7 +24,7 @@ typedef struct {
   int32_t src_buf, dst_buf;
   int64_t src_off, dst_off;
   int64_t extent[3], ss[3], ds[3];
-  int32_t peer, reserved;
+  int32_t peer, row_pitch; /* row_pitch > 0: the move writes whole interior rows of the destination pencil, whose row pitch this is (csrc/plan.h dst_row_pitch) */
 } cudecompExtMove_t;
 
 typedef struct {
@@ -216,7 +216,8 @@ cudecompResult_t cudecompExtEstimateCycleMs(cudecompHandle_t handle, const cudec
  * (non-temporal) variants that are normally used only for moves of 32 MiB and more, 4 selects the window variant of
  * the LDS transpose for every destination off the 64-byte grid (normally only for moves of 1 MiB and more), 8 disables
  * it; 16 / 32: 128 x 64 / 64 x 64 tiles for 4-byte transposes (tuning variants; the default is 64 x 128); 64 / 128: transposes walk
- * their tiles i first / j first (without runs).  *kernel_class (optional) receives the
+ * their tiles i first / j first (without runs); 256: the move covers whole rows of a halo-carrying destination, the cells between
+ * consecutive rows may be rewritten with their own content (dense row copy).  *kernel_class (optional) receives the
  * kernel flavour used: 0 rows, 1 LDS transpose, 2 generic. */
 cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const int64_t extent[3],
                                    const int64_t ss[3], const int64_t ds[3], int32_t force_generic,
@@ -225,7 +226,9 @@ cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const
 /* How the kernel layer WOULD execute a 3-D block move between buffers at the given addresses (no launch; works without a
  * GPU): out[10] = {class (0 rows, 1 LDS transpose, 2 generic), kernel variant, tile_i, tile_j, tiles_i, tiles_j, batch extent,
  * run length of the tile walk, walk bits (1 XCD-contiguous, 2 j first, 4 runs over batch planes), access mode}.  flags: 2 =
- * streaming access regardless of the size, 64 / 128 = force the i-first / j-first walk.  Harness-only (tests/test_kernel_plan.py). */
+ * streaming access regardless of the size, 4 = window / shifted variants regardless of the size, 64 / 128 = force the i-first /
+ * j-first walk, 256 = whole destination rows (as cudecompExtMove3D).  Row copies report their kernel in the tile_i slot
+ * (0 plain, 1 shifted, 2 dense).  Harness-only (tests/test_kernel_plan.py). */
 cudecompResult_t cudecompExtDescribeMove(uint64_t src_address, uint64_t dst_address, int32_t es, const int64_t extent[3],
                                         const int64_t ss[3], const int64_t ds[3], int32_t flags, int64_t out[10]);
 

@@ -8,8 +8,13 @@
 //   full      whole units are written at the row ends too (the bytes outside the row -- halo cells of the pencil -- are read
 //             from the destination first and written back unchanged)
 //   aligned   pitch 8192, no offset: the ceiling
-// Also: source aligned vs. source shifted like the destination.
+// Also: source aligned vs. source shifted like the destination; "dense": the linear walk across row ends (whole lines, gap bytes
+// rewritten unchanged) that became rows_dense_kernel; and the library's own shifted / dense kernels on the same buffers.
+//   build:  make -C ../../cudecomp_amd && hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../cudecomp_amd/csrc -I../../include -c partial_probe.hip -o pp.o \
+//             && hipcc --offload-arch=gfx950 pp.o ../../cudecomp_amd/build/{kernels,plan,decomp}.o ../../cudecomp_amd/build/kernels_*.hip.o -o partial_probe
 #include <hip/hip_runtime.h>
+
+#include "kernels.h"  // the library's dispatch (linked from cudecomp_amd/build/*.o): rows_shifted_kernel / rows_dense_kernel themselves
 
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +86,93 @@ __global__ __launch_bounds__(256) void copy_k(const char* __restrict__ src, char
   }
 }
 
+
+// MODE 3 "dense" (round 5, last GPU calls): the lanes walk the destination's LINEAR address space on the 64-byte grid, across
+// row boundaries: every store is a whole aligned vector and every wavefront instruction writes 1 KiB of whole lines.  Bytes of
+// the gaps between rows (halo cells of the same pencil) are read from the destination and written back unchanged; nothing is
+// touched below the first row's first byte or above the last row's last byte (masked pieces there).  spitch: the source's own
+// row pitch (8192 = a dense receive area, the unpack case).
+__global__ __launch_bounds__(256) void dense_k(const char* __restrict__ src, char* __restrict__ dst, long long rows, long long pitch,
+                                               long long spitch, long long row_bytes, long long doff, long long soff, double inv_pitch) {
+  char* d0 = dst + doff;  // first byte of row 0
+  const long long shift = (long long)(reinterpret_cast<uintptr_t>(d0) & 63);
+  const long long span = (rows - 1) * pitch + row_bytes;  // bytes from row 0's first to the last row's last byte
+  u32x4 v[4];
+  long long pos[4];
+  int kind[4];  // 0 nothing, 1 whole vector, 2 mixed (v holds the merged vector), 3 edge of the span (pieces)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long q = ((long long)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+    const long long p = q * 16 - shift;
+    pos[u] = p;
+    kind[u] = 0;
+    if (p >= span || p + 16 <= 0) continue;
+    long long r = (long long)((double)(p < 0 ? 0 : p) * inv_pitch);
+    long long o = p - r * pitch;
+    if (o < 0) { --r; o += pitch; } else if (o >= pitch) { ++r; o -= pitch; }
+    if (p >= 0 && o + 16 <= row_bytes) {
+      kind[u] = 1;
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_g*>(src + r * spitch + soff + o));
+    } else {
+      kind[u] = (p >= 0 && p + 16 <= span) ? 2 : 3;
+      unsigned int* wp = reinterpret_cast<unsigned int*>(&v[u]);
+      for (int k = 0; k < 4; ++k) {
+        const long long pp = p + 4 * k;
+        if (pp < 0 || pp >= span) { wp[k] = 0; continue; }
+        long long rr = r, oo = o + 4 * k;
+        if (oo >= pitch) { ++rr; oo -= pitch; }
+        wp[k] = oo < row_bytes ? *reinterpret_cast<const unsigned int*>(src + rr * spitch + soff + oo) : *reinterpret_cast<const unsigned int*>(d0 + pp);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (kind[u] == 1 || kind[u] == 2) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(d0 + pos[u]));
+    else if (kind[u] == 3) {
+      const unsigned int* wp = reinterpret_cast<const unsigned int*>(&v[u]);
+      for (int k = 0; k < 4; ++k) {
+        const long long pp = pos[u] + 4 * k;
+        if (pp >= 0 && pp < span) *reinterpret_cast<unsigned int*>(d0 + pp) = wp[k];
+      }
+    }
+  }
+}
+float timeDense(const char* src, char* dst, long long rows, long long pitch, long long spitch, long long row_bytes, long long doff, long long soff) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const long long span = (rows - 1) * pitch + row_bytes + 64;
+  const unsigned blocks = (unsigned)((span + 16383) / 16384);
+  dense_k<<<blocks, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 10; ++i) dense_k<<<blocks, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / 10;
+}
+// the dense kernel's result, every byte: rows = source rows, gaps and everything outside the span = the destination's previous content
+__global__ void fill_k(unsigned int* p, unsigned long long n, unsigned int salt) {
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+    p[i] = (unsigned int)(i * 2654435761u) ^ salt;
+}
+__global__ void check_k(const unsigned int* src, const unsigned int* dst, unsigned long long ndw, long long rows, long long pitch, long long spitch,
+                        long long row_bytes, long long doff, long long soff, unsigned int salt, unsigned long long* bad) {
+  unsigned long long mine = 0;
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < ndw; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const long long p = (long long)i * 4 - doff;
+    unsigned int want = (unsigned int)(i * 2654435761u) ^ salt;  // untouched
+    if (p >= 0) {
+      const long long r = p / pitch, o = p % pitch;
+      if (r < rows && o < row_bytes) want = src[(r * spitch + soff + o) / 4];
+    }
+    if (dst[i] != want) ++mine;
+  }
+  if (mine) atomicAdd(bad, mine);
+}
+
 template <int MODE>
 float timeIt(const char* src, char* dst, long long rows, long long pitch, long long row_bytes, long long doff, long long soff) {
   hipEvent_t e0, e1;
@@ -132,6 +224,60 @@ int main() {
     printf("  partial units written as pieces : %.3f ms %6.0f GB/s\n", a, bytes / a / 1e6);
     printf("  partial units skipped           : %.3f ms %6.0f GB/s\n", b, bytes / b / 1e6);
     printf("  end units written whole (RMW)   : %.3f ms %6.0f GB/s\n", f, bytes / f / 1e6);
+    {  // dense: checked byte by byte first (pattern data), then timed; source with the same pitch, and with its own dense pitch
+      for (long long spitch : {c.pitch, (long long)8192}) {
+        const unsigned long long ndw = cap / 4;
+        fill_k<<<8192, 256>>>(reinterpret_cast<unsigned int*>(src), ndw, 0x12345678u);
+        fill_k<<<8192, 256>>>(reinterpret_cast<unsigned int*>(dst), ndw, 0x9abcdef0u);
+        dense_k<<<(unsigned)(((rows - 1) * c.pitch + row_bytes + 64 + 16383) / 16384), 256>>>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff,
+                                                                                             1.0 / (double)c.pitch);
+        unsigned long long* bad;
+        CK(hipMalloc(&bad, 8));
+        CK(hipMemset(bad, 0, 8));
+        check_k<<<8192, 256>>>(reinterpret_cast<const unsigned int*>(src), reinterpret_cast<const unsigned int*>(dst), ndw, rows, c.pitch, spitch,
+                               row_bytes, c.doff, soff, 0x9abcdef0u, bad);
+        unsigned long long nbad = 1;
+        CK(hipMemcpy(&nbad, bad, 8, hipMemcpyDeviceToHost));
+        CK(hipFree(bad));
+        float dn = timeDense(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff);
+        printf("  dense linear walk, gaps RMW, source pitch %lld : %.3f ms %6.0f GB/s   (%llu wrong dwords)\n", spitch, dn, bytes / dn / 1e6, nbad);
+      }
+      CK(hipMemset(src, 1, cap));
+      CK(hipMemset(dst, 2, cap));
+    }
+  }
+  {  // the LIBRARY's kernels on the same buffers (pattern data): plain / shifted / dense, source pitch 8192 and 8208
+    using namespace cudecomp;
+    fill_k<<<8192, 256>>>(reinterpret_cast<unsigned int*>(src), cap / 4, 0x12345678u);
+    fill_k<<<8192, 256>>>(reinterpret_cast<unsigned int*>(dst), cap / 4, 0x9abcdef0u);
+    for (long long sp : {1024ll, 1026ll})
+      for (long long dp : {1024ll, 1026ll, 1028ll})
+        for (int whole = 0; whole < 2; ++whole) {
+          Move3D m;
+          m.src_buf = BUF_IN;
+          m.dst_buf = BUF_OUT;
+          m.extent[0] = 1024; m.extent[1] = rows; m.extent[2] = 1;
+          m.ss[0] = 1; m.ss[1] = sp; m.ss[2] = 0;
+          m.ds[0] = 1; m.ds[1] = dp; m.ds[2] = 0;
+          m.dst_off = dp == 1024 ? 0 : 1;
+          m.dst_row_pitch = whole ? dp : 0;
+          void* bufs[3] = {src, dst, nullptr};
+          hipEvent_t e0, e1;
+          CK(hipEventCreate(&e0));
+          CK(hipEventCreate(&e1));
+          KernelTuning kt;
+          launchMoves(&m, 1, bufs, 8, nullptr, &kt);
+          CK(hipDeviceSynchronize());
+          CK(hipEventRecord(e0));
+          for (int i = 0; i < 10; ++i) launchMoves(&m, 1, bufs, 8, nullptr, &kt);
+          CK(hipEventRecord(e1));
+          CK(hipDeviceSynchronize());
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          ms /= 10;
+          printf("library: source pitch %lld B, destination pitch %lld B (+%lld B), whole rows %d: %-28s %.3f ms %6.0f GB/s\n", sp * 8, dp * 8,
+                 (long long)m.dst_off * 8, whole, lastKernelName(), ms, bytes / ms / 1e6);
+        }
   }
   return 0;
 }

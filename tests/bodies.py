@@ -89,7 +89,7 @@ def run_moves(moves, n, bufs):
 def stage_of_move(m, axis, k, K):
     """python twin of csrc/plan.cc stageOfMove: range k of K of the move's extent along global axis `axis`"""
     r = cd.ExtMove()
-    for f in ("src_buf", "dst_buf", "src_off", "dst_off", "peer", "reserved"):
+    for f in ("src_buf", "dst_buf", "src_off", "dst_off", "peer", "row_pitch"):
         setattr(r, f, getattr(m, f))
     n = m.extent[axis]
     lo, hi = n * k // K, n * (k + 1) // K

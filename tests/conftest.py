@@ -45,7 +45,7 @@ def golden_dir():
 # before the next rank-launching test starts.  Round 3 ordered the suite around the problem instead
 # (pytest_collection_modifyitems); that hook is gone.  CUDECOMP_TEST_NO_FORK=1 runs everything in this process.
 _INPROCESS_GPU_MODULES = ("test_gpu_autotune", "test_gpu_halo", "test_gpu_kernels", "test_gpu_transpose",
-                          "test_inprocess_isolation")
+                          "test_gpu_dense_rows", "test_inprocess_isolation")
 
 
 def _inprocess(item):

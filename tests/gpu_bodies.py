@@ -119,6 +119,62 @@ def single_transpose(rank, nranks, args):
     return transpose_chain(rank, nranks, a)
 
 
+def transpose_every_byte(rank, nranks, args):
+    """Transposes onto halo-carrying / padded pencils with EVERY BYTE of the destination buffer compared: interior cells as the
+    analytic oracle says, everything else (halo cells, padding, the tail of the buffer) exactly what it held before the call.
+    The reference's tests compare the interior only (tests/ctest/transpose_tests.cc:356-378); the dense row copy
+    (rows_dense_kernel) reads the cells between consecutive rows and writes them back, which this check would catch doing
+    anything else.  args["expect_kernel"]: {op: substring of the name of the last kernel the op must have launched}."""
+    h, gd, g = _setup(rank, nranks, args)
+    kind = args.get("kind", 1)
+    dt, es = orc.KINDS[kind]
+    halos, pads = args["halos"], args["pads"]
+    pin = [cd.cudecompGetPencilInfo(h, gd, ax, halos[ax], pads[ax]) for ax in range(3)]
+    opin = [g.pencil_info(rank, ax, halos[ax], pads[ax]) for ax in range(3)]
+    nel = max(p.size for p in pin) + 64
+    wsz = cd.cudecompGetTransposeWorkspaceSize(h, gd)
+    work_ptr = cd.cudecompMalloc(h, gd, wsz * es)
+    failures = []
+    rng = np.random.default_rng(1234 + rank)
+    for oop in args.get("out_of_place", [True, False]):
+        a = G.to_device(rng.integers(0, 256, nel * es, dtype=np.uint8))
+        b = G.to_device(rng.integers(0, 256, nel * es, dtype=np.uint8)) if oop else a
+        ops = args.get("ops", list(cd.OPS))
+        first_ax = orc.OP_AXES[ops[0]][0]
+        init = G.to_host(a).view(dt).copy()
+        init[:pin[first_ax].size] = g.fill_pencil(opin[first_ax], kind)
+        a.copy_(torch.from_numpy(init.view(np.uint8)))
+        cur, nxt = a, b
+        for op in ops:
+            ai, ao = orc.OP_AXES[op]
+            before = G.to_host(nxt).view(dt).copy()
+            cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work_ptr, cd.DTYPE_OF_KIND[kind], halos[ai],
+                                 halos[ao], pads[ai], pads[ao], G.stream_ptr())
+            torch.cuda.synchronize()
+            last = cd.cudecompExtLastKernelName()
+            got = G.to_host(nxt).view(dt)
+            exp = g.fill_pencil(opin[ao], kind)
+            interior = np.real(exp) != -1  # (cells outside the interior are filled with -1 / (-1, -1))
+            want = before.copy()
+            want[:pin[ao].size][interior] = exp[interior]
+            if not np.array_equal(got.view(np.uint8), want.view(np.uint8)):
+                gb, wb = got.view(np.uint8).reshape(-1, es), want.view(np.uint8).reshape(-1, es)
+                bad = np.nonzero((gb != wb).any(axis=1))[0]
+                where = "interior" if (bad[0] < pin[ao].size and interior[bad[0]]) else "OUTSIDE the interior"
+                failures.append("rank %d oop=%s %s: %d cells differ, first at %d (%s; want %r got %r); last kernel %s" %
+                                (rank, oop, op, bad.size, bad[0], where, want[bad[0]], got[bad[0]], last))
+                break
+            need = (args.get("expect_kernel") or {}).get(op)
+            if need and need not in last:
+                failures.append("rank %d oop=%s %s: last kernel %r, expected %r" % (rank, oop, op, last, need))
+            if oop:
+                cur, nxt = nxt, cur
+    torch.cuda.synchronize()
+    cd.cudecompFree(h, gd, work_ptr)
+    cd.cudecompGridDescDestroy(h, gd)
+    return failures
+
+
 def halo_sweep(rank, nranks, args):
     """UpdateHalos{X,Y,Z} for dim 0,1,2 in sequence, whole-buffer compare."""
     h, gd, g = _setup(rank, nranks, args)

@@ -23,7 +23,9 @@ def run_move(es, extent, ss, ds, src_len, dst_len, src_off=0, dst_off=0, seed=0,
     # streaming) for every destination off the 64-byte grid; 4-byte elements: the tile-shape switches (they select other
     # tiles only in `make TUNING_VARIANTS=1` builds, the default build always uses 64 x 128); the diagnostic store policy /
     # tile walk of the shared-GPU hunt
-    for force_generic in (0, 1, 2, 4, 6) + ((16, 32, 18, 34) if es == 4 else ()) + (64, 128 + 2):
+    # 256: "the cells between consecutive destination rows are the move's" -> row copies onto rows off the 64-byte grid take the
+    # dense walk (rows_dense_kernel) when the gap is a few cells; every byte of the destination is compared either way
+    for force_generic in (0, 1, 2, 4, 6) + ((16, 32, 18, 34) if es == 4 else ()) + (64, 128 + 2, 256 + 4, 256 + 4 + 2):
         d_src, d_dst = G.to_device(src.view(np.uint8)), G.to_device(dst0.view(np.uint8))
         cls = cd.cudecompExtMove3D(d_src.data_ptr() + src_off * es, d_dst.data_ptr() + dst_off * es, es, extent, ss, ds,
                                    force_generic, G.stream_ptr())

@@ -113,3 +113,87 @@ def test_run_walks_by_hand():
     for ti_n, tj_n, batch, run, bits in [(3, 8, 2, 4, 3), (5, 12, 1, 6, 3), (2, 3, 8, 4, 7), (4, 5, 6, 2, 7), (3, 7, 5, 0, 3), (3, 7, 5, 0, 1),
                                          (16, 64, 1, 8, 2)]:
         check_bijection({"tiles_i": ti_n, "tiles_j": tj_n, "batch": batch, "run": run, "walk": bits})
+
+
+# ---- row copies of whole rows onto halo-carrying pencils: the dense walk (rows_dense_kernel, csrc/kernels_rows.hip) -----------
+WHOLE = 256  # cudecompExtDescribeMove / cudecompExtMove3D flag: the cells between consecutive destination rows are the move's
+
+
+def test_dense_row_copy_is_chosen_only_where_it_is_safe_and_pays():
+    nx, ny, nz = 1024, 128, 4  # fp64: 4 MiB
+    src_st = (1, nx, nx * ny)
+    halo_st = (1, nx + 2, (nx + 2) * (ny + 2))  # a halo of one cell on x and y: rows 8 B off the 64-byte grid, 16-byte gaps
+    d = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (nx, ny, nz), src_st, halo_st, flags=WHOLE)
+    assert d["cls"] == 0 and d["tile_i"] == 2 and d["variant"] == 16, d
+    span = (ny - 1) * (nx + 2) * 8 + nx * 8
+    assert d["batch"] == nz and d["tiles_i"] == -(-(span + 63) // 16384) and d["tiles_j"] == 1, d
+    # without the planner's word: the shifted kernel (partial lines at the row ends)
+    assert cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (nx, ny, nz), src_st, halo_st)["tile_i"] == 1
+    # small moves keep the plain kernel unless asked (flag 4), as for the shifted kernel
+    assert cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (nx, 8, 2), src_st, halo_st, flags=WHOLE)["tile_i"] == 0
+    assert cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (nx, 8, 2), src_st, halo_st, flags=WHOLE | 4)["tile_i"] == 2
+    # gaps wider than a few cells (a slab out of a wider pencil) are not rewritten
+    wide = (1, 2 * nx, 2 * nx * ny)
+    assert cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (nx, ny, nz), src_st, wide, flags=WHOLE)["tile_i"] == 1
+    # one row per plane: the next row of the MOVE is a plane away, other rows lie in between
+    one = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (nx, 1, 512), (1, nx, nx), halo_st, flags=WHOLE)
+    assert one["tile_i"] == 1, one
+    # line-aligned rows (the gap is whole lines) need neither
+    aligned = (1, nx + 16, (nx + 16) * ny)
+    assert cd.cudecompExtDescribeMove(SRC, DST, 8, (nx, ny, nz), src_st, aligned, flags=WHOLE)["tile_i"] == 0
+    # rows that fuse with the next dim (no gap on x, halo rows on y only) are long rows, not "whole rows"
+    yhalo = (1, nx, nx * (ny + 2))
+    f = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (nx, ny, nz), src_st, yhalo, flags=WHOLE)
+    assert f["cls"] == 0 and f["tile_i"] == 1, f
+    # the two slower dims in the other order on the source side (a chunk in another wire order): dim 1 is still the one that
+    # steps by the row pitch
+    swapped = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (nx, ny, nz), (1, nx * nz, nx), halo_st, flags=WHOLE)
+    assert swapped["tile_i"] == 2 and swapped["batch"] == nz, swapped
+    # 4- and 16-byte elements alike
+    for es in (4, 16):
+        assert cd.cudecompExtDescribeMove(SRC, DST + es, es, (nx, ny, nz), src_st, halo_st, flags=WHOLE)["tile_i"] == 2
+
+
+def dense_walk_reference(src, dst, row_bytes, rows, pitch, spitch, dst_base_address, per_block=16384):
+    """numpy restatement of rows_dense_kernel for ONE plane, byte arrays: src row r at r*spitch, dst row r at
+    dst_base_address-relative offset `d0` + r*pitch.  Returns the set of destination bytes written and performs the copy the
+    way the lanes do (16-byte vectors on the 64-byte grid; gap bytes re-written with their own content; masked ends)."""
+    d0 = dst_base_address
+    shift = d0 & 63
+    span = (rows - 1) * pitch + row_bytes
+    blocks = -(-(span + 63) // per_block)
+    written = np.zeros(dst.size, dtype=bool)
+    out = dst.copy()
+    for vec in range(blocks * per_block // 16):
+        p = vec * 16 - shift
+        if p >= span or p + 16 <= 0:
+            continue
+        for k in range(4):
+            pp = p + 4 * k
+            if pp < 0 or pp >= span:
+                continue
+            r, o = divmod(pp, pitch)
+            val = src[r * spitch + o:r * spitch + o + 4] if o < row_bytes else dst[d0 + pp:d0 + pp + 4]
+            out[d0 + pp:d0 + pp + 4] = val
+            written[d0 + pp:d0 + pp + 4] = True
+    return out, written
+
+
+def test_dense_walk_restatement_copies_rows_and_leaves_everything_else():
+    rng = np.random.default_rng(7)
+    for _ in range(40):
+        row_bytes = int(rng.integers(64, 130)) * 4
+        gap = int(rng.integers(1, 9)) * 4
+        rows = int(rng.integers(2, 9))
+        pitch = row_bytes + gap
+        spitch = row_bytes + int(rng.integers(0, 3)) * 4
+        d0 = int(rng.integers(0, 40)) * 4
+        src = rng.integers(0, 256, rows * spitch + 64, dtype=np.uint8)
+        dst = rng.integers(0, 256, d0 + rows * pitch + 128, dtype=np.uint8)
+        out, written = dense_walk_reference(src, dst, row_bytes, rows, pitch, spitch, d0, per_block=1024)
+        exp = dst.copy()
+        for r in range(rows):
+            exp[d0 + r * pitch:d0 + r * pitch + row_bytes] = src[r * spitch:r * spitch + row_bytes]
+        assert np.array_equal(out, exp)
+        span = (rows - 1) * pitch + row_bytes
+        assert written[d0:d0 + span].all() and not written[:d0].any() and not written[d0 + span:].any()

@@ -52,6 +52,55 @@ def _regions_disjoint(a0, a1, b0, b1):
     return a1 <= b0 or b1 <= a0 or a0 == a1 or b0 == b1
 
 
+def _cells(m, off_key, st_key):
+    """flat indices (elements) a move touches on one side"""
+    e = list(m.extent)
+    st_ = list(getattr(m, st_key))
+    k = np.indices(e).reshape(3, -1)
+    return getattr(m, off_key) + k[0] * st_[0] + k[1] * st_[1] + k[2] * st_[2]
+
+
+def check_rows_whole_moves(plan, out_len):
+    """Move3D::dst_row_pitch (csrc/plan.h): the kernel layer may REWRITE the cells between destination rows of such a move that
+    are one row pitch apart (rows_dense_kernel reads them and writes them back inside whole cache lines).  That is only
+    harmless when nobody else writes them during the operation: here, no other move of the rank's plan (pack or unpack) that
+    targets the output pencil -- and the spans stay inside the pencil."""
+    moves = [plan.pack[i] for i in range(plan.n_pack)] + [plan.unpack[i] for i in range(plan.n_unpack)]
+    moves = [m for m in moves if 0 not in list(m.extent)]
+    writers = np.zeros(out_len, dtype=np.int32)
+    for m in moves:
+        if m.dst_buf == 1:
+            writers[_cells(m, "dst_off", "ds")] += 1
+    assert writers.max(initial=0) <= 1, "two moves of one plan write the same output cell"
+    n_checked = 0
+    for m in moves:
+        if m.row_pitch <= 0:
+            continue
+        assert m.dst_buf == 1, "dst_row_pitch on a move that does not target the output pencil"
+        e, ds = list(m.extent), list(m.ds)
+        rows = [i for i in range(3) if ds[i] == 1]
+        assert len(rows) == 1 and e[rows[0]] > 1, "whole rows, but no single unit-stride dim with more than one element"
+        i0 = rows[0]
+        assert m.row_pitch >= e[i0]
+        r = [i for i in range(3) if i != i0 and ds[i] == m.row_pitch and e[i] > 1]
+        if not r:
+            continue  # one row per plane: nothing is a row pitch apart (the kernel layer keeps its row-by-row kernels)
+        r = r[0]
+        q = 3 - i0 - r
+        span = (e[r] - 1) * ds[r] + e[i0]
+        assert e[q] == 1 or span <= ds[q], "planes of a whole-rows move interleave"
+        n_checked += 1
+        for kq in range(e[q]):
+            base = m.dst_off + kq * ds[q]
+            assert 0 <= base and base + span <= out_len, "span of a whole-rows move leaves the pencil"
+            in_rows = np.zeros(span, dtype=bool)
+            for kr in range(e[r]):
+                in_rows[kr * ds[r]:kr * ds[r] + e[i0]] = True
+            gap = base + np.nonzero(~in_rows)[0]
+            assert not writers[gap].any(), "cells between the rows of a whole-rows move are written by another move"
+    return n_checked
+
+
 def simulate_transpose(d, op, halos, pads, inplace, pipelined, symmetric, npergroup):
     spec, g = _grids(d)
     n = g.nranks
@@ -61,6 +110,8 @@ def simulate_transpose(d, op, halos, pads, inplace, pipelined, symmetric, npergr
     wsz = g.transpose_workspace_size()
     plans = [cd.cudecompExtPlanTranspose(spec, r, op, halos[0], halos[1], pads[0], pads[1], inplace, pipelined,
                                          symmetric, npergroup) for r in range(n)]
+    for r in range(n):
+        check_rows_whole_moves(plans[r], max(pa[r].size, pb[r].size))
     bufs = []
     for r in range(n):
         nel = max(pa[r].size, pb[r].size)
