@@ -465,6 +465,39 @@ def extras_single_gpu(cd, torch, h, stream):
                                "per_dim": res}
     except Exception as e:
         out["config5_halo"] = {"error": str(e)[:200]}
+    try:
+        # transposes ONTO halo-carrying pencils (solvers that keep halos around their pencils): 1 x 1 grid, both layouts, 1024^3
+        # fp64 with a halo of one cell on every pencil.  Default layout: every hop is one row copy of whole rows (rows_dense_kernel:
+        # whole cache lines across the row ends); axis-contiguous: permutations onto rows off the 64-byte grid (window kernel).
+        halo, n, res = (1, 1, 1), 1024, {}
+        for layout, ac in (("default", (0, 0, 0)), ("contiguous", (1, 1, 1))):
+            gd = cd.cudecompGridDescCreate(h, cd.make_config((n, n, n), (1, 1), axis_contiguous=ac))
+            nel = max(cd.cudecompGetPencilInfo(h, gd, ax, halo).size for ax in range(3))
+            a = torch.zeros(nel, dtype=torch.float64, device="cuda")
+            b = torch.zeros(nel, dtype=torch.float64, device="cuda")
+            work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * 8)
+            ops = {}
+            for op in cd.OPS:
+                for _ in range(2):
+                    cd.cudecompTranspose(op, h, gd, a.data_ptr(), b.data_ptr(), work, cd.DOUBLE, halo, halo, None, None, stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    cd.cudecompTranspose(op, h, gd, a.data_ptr(), b.data_ptr(), work, cd.DOUBLE, halo, halo, None, None, stream)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 5
+                ops[op] = {"ms": round(ms, 4), "frac": round(2 * 8 * n**3 / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                           "kernel": cd.cudecompExtLastKernelName()}
+            res[layout] = ops
+            cd.cudecompFree(h, gd, work)
+            cd.cudecompGridDescDestroy(h, gd)
+            del a, b
+        out["halo_pencil_transposes"] = {"workload": "transposes onto halo-carrying pencils: 1024^3 fp64, halo (1,1,1) on every pencil, "
+                                                     "1x1 grid, out of place, 2 warm-up + 5 timed per op; frac = 2 x 8 GiB / ms / 8 TB/s",
+                                         "per_layout": res}
+    except Exception as e:
+        out["halo_pencil_transposes"] = {"error": str(e)[:200]}
     return out
 
 

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void copy_k(const char* __restrict__ src, char
 // the gaps between rows (halo cells of the same pencil) are read from the destination and written back unchanged; nothing is
 // touched below the first row's first byte or above the last row's last byte (masked pieces there).  spitch: the source's own
 // row pitch (8192 = a dense receive area, the unpack case).
+template <int BAR>
 __global__ __launch_bounds__(256) void dense_k(const char* __restrict__ src, char* __restrict__ dst, long long rows, long long pitch,
                                                long long spitch, long long row_bytes, long long doff, long long soff, double inv_pitch) {
   char* d0 = dst + doff;  // first byte of row 0
@@ -102,7 +103,11 @@ __global__ __launch_bounds__(256) void dense_k(const char* __restrict__ src, cha
   int kind[4];  // 0 nothing, 1 whole vector, 2 mixed (v holds the merged vector), 3 edge of the span (pieces)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const long long q = ((long long)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+    // mapping (BAR >> 1): 0 a workgroup covers 16 KiB contiguous (lane stride 4 KiB); 1 two workgroups interleave 4-KiB pieces of a
+    // 32-KiB chunk (lane stride 8 KiB, as rows_kernel on 8-KiB rows); 2 four workgroups interleave (lane stride 16 KiB)
+    const long long bx = blockIdx.x;
+    const long long q = (BAR >> 1) == 0 ? (bx * 4 + u) * 256 + threadIdx.x
+                        : ((BAR >> 1) == 1 ? ((bx / 2) * 8 + u * 2 + (bx % 2)) * 256 + threadIdx.x : ((bx / 4) * 16 + u * 4 + (bx % 4)) * 256 + threadIdx.x);
     const long long p = q * 16 - shift;
     pos[u] = p;
     kind[u] = 0;
@@ -125,6 +130,7 @@ __global__ __launch_bounds__(256) void dense_k(const char* __restrict__ src, cha
       }
     }
   }
+  if (BAR & 1) __syncthreads();  // (mode 5: all four wavefronts have their loads back before anybody stores)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     if (kind[u] == 1 || kind[u] == 2) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(d0 + pos[u]));
@@ -137,16 +143,120 @@ __global__ __launch_bounds__(256) void dense_k(const char* __restrict__ src, cha
     }
   }
 }
+
+// MODE 4 "dense2": the dense walk with ALIGNED loads -- each lane fetches the aligned 16-byte vector below its (misaligned)
+// source bytes, takes the next one from its neighbour lane (ds_bpermute; the wavefront's last lane from the next wavefront of
+// the workgroup through LDS) and funnel-shifts the two by the misalignment; lanes at row ends keep the unaligned load.
+__device__ __forceinline__ u32x4 shiftPair(const u32x4& L, const u32x4& H, int d) {  // dwords d .. d+3 of (L, H)
+  u32x4 r;
+  r.x = d == 0 ? L.x : (d == 1 ? L.y : (d == 2 ? L.z : L.w));
+  r.y = d == 0 ? L.y : (d == 1 ? L.z : (d == 2 ? L.w : H.x));
+  r.z = d == 0 ? L.z : (d == 1 ? L.w : (d == 2 ? H.x : H.y));
+  r.w = d == 0 ? L.w : (d == 1 ? H.x : (d == 2 ? H.y : H.z));
+  return r;
+}
+__global__ __launch_bounds__(256) void dense2_k(const char* __restrict__ src, char* __restrict__ dst, long long rows, long long pitch,
+                                                long long spitch, long long row_bytes, long long doff, long long soff, double inv_pitch) {
+  __shared__ u32x4 xch[4][4];
+  char* d0 = dst + doff;
+  const long long shift = (long long)(reinterpret_cast<uintptr_t>(d0) & 63);
+  const long long span = (rows - 1) * pitch + row_bytes;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 v[4], L[4];
+  long long pos[4];
+  const char* addr[4];
+  int kind[4];  // 0 nothing, 1 whole vector (v final), 2 span edge, 4 body with aligned load (needs the shift), 5 same, successor not usable
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long q = ((long long)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+    const long long p = q * 16 - shift;
+    pos[u] = p;
+    kind[u] = 0;
+    L[u] = u32x4{0, 0, 0, 0};
+    addr[u] = src;
+    if (p >= span || p + 16 <= 0) continue;
+    long long r = (long long)((double)(p < 0 ? 0 : p) * inv_pitch);
+    long long o = p - r * pitch;
+    if (o < 0) { --r; o += pitch; } else if (o >= pitch) { ++r; o -= pitch; }
+    if (p >= 0 && o + 16 <= row_bytes) {
+      const char* a = src + r * spitch + soff + o;
+      const int sh = (int)(reinterpret_cast<uintptr_t>(a) & 15);
+      addr[u] = a;
+      if (sh == 0) {
+        kind[u] = 1;
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a));
+        L[u] = v[u];
+      } else {
+        kind[u] = (o + 32 <= row_bytes) ? 4 : 5;
+        L[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a - sh));
+      }
+    } else {
+      kind[u] = (p >= 0 && p + 16 <= span) ? 1 : 2;
+      unsigned int* wp = reinterpret_cast<unsigned int*>(&v[u]);
+      for (int k = 0; k < 4; ++k) {
+        const long long pp = p + 4 * k;
+        if (pp < 0 || pp >= span) { wp[k] = 0; continue; }
+        long long rr = r, oo = o + 4 * k;
+        if (oo >= pitch) { ++rr; oo -= pitch; }
+        wp[k] = oo < row_bytes ? *reinterpret_cast<const unsigned int*>(src + rr * spitch + soff + oo) : *reinterpret_cast<const unsigned int*>(d0 + pp);
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xch[u][wave] = L[u];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    u32x4 H;
+    H.x = __shfl_down(L[u].x, 1);
+    H.y = __shfl_down(L[u].y, 1);
+    H.z = __shfl_down(L[u].z, 1);
+    H.w = __shfl_down(L[u].w, 1);
+    if (kind[u] < 4) continue;
+    const int sh = (int)(reinterpret_cast<uintptr_t>(addr[u]) & 15);
+    bool have = kind[u] == 4;
+    if (lane == 63 && have) {
+      if (wave < 3) H = xch[u][wave + 1];
+      else if (u < 3) H = xch[u + 1][0];
+      else have = false;
+    }
+    if (!have) H = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(addr[u] - sh + 16));
+    v[u] = shiftPair(L[u], H, sh >> 2);
+    kind[u] = 1;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (kind[u] == 1) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(d0 + pos[u]));
+    else if (kind[u] == 2) {
+      const unsigned int* wp = reinterpret_cast<const unsigned int*>(&v[u]);
+      for (int k = 0; k < 4; ++k) {
+        const long long pp = pos[u] + 4 * k;
+        if (pp >= 0 && pp < span) *reinterpret_cast<unsigned int*>(d0 + pp) = wp[k];
+      }
+    }
+  }
+}
+
+template <int V2>
 float timeDense(const char* src, char* dst, long long rows, long long pitch, long long spitch, long long row_bytes, long long doff, long long soff) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const long long span = (rows - 1) * pitch + row_bytes + 64;
   const unsigned blocks = (unsigned)((span + 16383) / 16384);
-  dense_k<<<blocks, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+  auto go = [&]() {
+    if (V2 == 1) dense2_k<<<blocks, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+    else if (V2 == 2) dense_k<1><<<blocks, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+    else if (V2 == 3) dense_k<2><<<(blocks + 3) / 4 * 4, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+    else if (V2 == 4) dense_k<4><<<(blocks + 3) / 4 * 4, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+    else dense_k<0><<<blocks, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+  };
+  go();
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < 10; ++i) dense_k<<<blocks, 256>>>(src, dst, rows, pitch, spitch, row_bytes, doff, soff, 1.0 / (double)pitch);
+  for (int i = 0; i < 10; ++i) go();
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms;
@@ -225,12 +335,17 @@ int main() {
     printf("  partial units skipped           : %.3f ms %6.0f GB/s\n", b, bytes / b / 1e6);
     printf("  end units written whole (RMW)   : %.3f ms %6.0f GB/s\n", f, bytes / f / 1e6);
     {  // dense: checked byte by byte first (pattern data), then timed; source with the same pitch, and with its own dense pitch
+      for (int v2 = 0; v2 < 5; ++v2)
       for (long long spitch : {c.pitch, (long long)8192}) {
         const unsigned long long ndw = cap / 4;
         fill_k<<<8192, 256>>>(reinterpret_cast<unsigned int*>(src), ndw, 0x12345678u);
         fill_k<<<8192, 256>>>(reinterpret_cast<unsigned int*>(dst), ndw, 0x9abcdef0u);
-        dense_k<<<(unsigned)(((rows - 1) * c.pitch + row_bytes + 64 + 16383) / 16384), 256>>>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff,
-                                                                                             1.0 / (double)c.pitch);
+        const unsigned nblk = (unsigned)(((rows - 1) * c.pitch + row_bytes + 64 + 16383) / 16384);
+        if (v2 == 1) dense2_k<<<nblk, 256>>>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff, 1.0 / (double)c.pitch);
+        else if (v2 == 2) dense_k<1><<<nblk, 256>>>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff, 1.0 / (double)c.pitch);
+        else if (v2 == 3) dense_k<2><<<(nblk + 3) / 4 * 4, 256>>>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff, 1.0 / (double)c.pitch);
+        else if (v2 == 4) dense_k<4><<<(nblk + 3) / 4 * 4, 256>>>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff, 1.0 / (double)c.pitch);
+        else dense_k<0><<<nblk, 256>>>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff, 1.0 / (double)c.pitch);
         unsigned long long* bad;
         CK(hipMalloc(&bad, 8));
         CK(hipMemset(bad, 0, 8));
@@ -239,8 +354,12 @@ int main() {
         unsigned long long nbad = 1;
         CK(hipMemcpy(&nbad, bad, 8, hipMemcpyDeviceToHost));
         CK(hipFree(bad));
-        float dn = timeDense(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff);
-        printf("  dense linear walk, gaps RMW, source pitch %lld : %.3f ms %6.0f GB/s   (%llu wrong dwords)\n", spitch, dn, bytes / dn / 1e6, nbad);
+        float dn = v2 == 1 ? timeDense<1>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff)
+                           : (v2 == 2 ? timeDense<2>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff)
+                           : (v2 == 3 ? timeDense<3>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff)
+                           : (v2 == 4 ? timeDense<4>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff) : timeDense<0>(src, dst, rows, c.pitch, spitch, row_bytes, c.doff, soff))));
+        printf("  dense linear walk%s, gaps RMW, source pitch %lld : %.3f ms %6.0f GB/s   (%llu wrong dwords)\n", v2 == 1 ? " + ALIGNED loads (lane shift)" : (v2 == 2 ? " + BARRIER between loads and stores" : (v2 == 3 ? " two workgroups interleaved (lane stride 8 KiB)" : (v2 == 4 ? " four workgroups interleaved (lane stride 16 KiB)" : ""))),
+               spitch, dn, bytes / dn / 1e6, nbad);
       }
       CK(hipMemset(src, 1, cap));
       CK(hipMemset(dst, 2, cap));
