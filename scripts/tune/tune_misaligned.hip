@@ -25,6 +25,7 @@ typedef d2 __attribute__((aligned(8))) d2u;
 
 struct Shape {
   long long ei, ej, ek, sj, sk, di, dk, soff, doff;
+  unsigned run = 0;  // walk 5: batch planes per run (all j tiles, `run` planes, then the tile rows i, then the next planes)
 };
 
 template <int TI, int TJ, int LDM, int STM, int JFIRST, int L = 16, int NTHR = 256>
@@ -42,6 +43,10 @@ __global__ __launch_bounds__(NTHR) void win_kernel(const double* __restrict__ sr
     bj = lb % tj_n; rest = lb / tj_n; bi = rest % ti_n; rest /= ti_n;
   } else if (JFIRST == 0) {
     bi = lb % ti_n; rest = lb / ti_n; bj = rest % tj_n; rest /= tj_n;
+  } else if (JFIRST == 5) {  // the library's run walk for far-strided destinations (transpose_kernel, p1 bit 4), over batch planes
+    bj = lb % tj_n; rest = lb / tj_n;
+    const unsigned klo = rest % s.run; rest /= s.run;
+    bi = rest % ti_n; rest = (rest / ti_n) * s.run + klo;
   } else {
     // blocked walk: BI x BJ tiles form a block that is walked first (i fastest inside), then blocks along i, then j
     constexpr unsigned BI = JFIRST == 2 ? 4 : (JFIRST == 3 ? 8 : 2), BJ = JFIRST == 2 ? 4 : (JFIRST == 3 ? 2 : 8);
@@ -219,6 +224,7 @@ struct Ctx {
   Shape s;
   int variant;
   cudecomp::KernelTuning tuning;
+  unsigned runs[3] = {1, 1, 1};
 };
 
 template <int TI, int TJ, int LDM, int STM, int JF, int L = 16, int NTHR = 256>
@@ -268,6 +274,9 @@ static void run(void* p) {
     case 19: launchWin<64, 128, 0, 1, 1, 8, 512>(c); break;
     case 20: launchWin<128, 32, 0, 1, 1, 8, 512>(c); break;
     case 21: launchWin<64, 64, 0, 1, 1, 8, 512>(c); break;
+    case 22: c->s.run = c->runs[0]; launchWin<64, 64, 0, 1, 5, 8>(c); break;
+    case 23: c->s.run = c->runs[1]; launchWin<64, 64, 0, 1, 5, 8>(c); break;
+    case 24: c->s.run = c->runs[2]; launchWin<64, 64, 0, 1, 5, 8>(c); break;
   }
 }
 
@@ -317,7 +326,8 @@ int main() {
                       "win 64x64 c/NT 64B walk i-first", "win 64x64 c/NT 64B walk j-first", "win 64x64 c/NT 64B walk 4x4",
                       "win 64x64 c/NT 64B walk 8ix2j", "win 64x64 ALIGNED-LOADS/NT 64B i-first", "win 64x64 ALIGNED-LOADS/NT 64B j-first",
                       "win 128x64 512thr c/NT 64B j-first", "win 128x64 512thr c/NT 64B i-first", "win 128x32 256thr c/NT 64B j-first",
-                      "win 64x128 512thr c/NT 64B j-first", "win 128x32 512thr c/NT 64B j-first", "win 64x64 512thr c/NT 64B j-first"};
+                      "win 64x128 512thr c/NT 64B j-first", "win 128x32 512thr c/NT 64B j-first", "win 64x64 512thr c/NT 64B j-first",
+                      "win 64x64 c/NT 64B RUNS over planes (a)", "win 64x64 c/NT 64B RUNS over planes (b)", "win 64x64 c/NT 64B RUNS over planes (c)"};
   for (auto& c : cases) {
     const double bytes = 2.0 * c.s.ei * c.s.ej * c.s.ek * 8;
     printf("== %s: %lld x %lld x %lld, %.2f GB per launch\n", c.name, c.s.ei, c.s.ej, c.s.ek, bytes / 1e9);
@@ -325,8 +335,22 @@ int main() {
     CK(hipMemset(ref, 0, n * 8));
     run(&ctx);  // reference result from the library kernel
     CK(hipDeviceSynchronize());
-    for (int v = (getenv("TUNE_FROM") ? atoi(getenv("TUNE_FROM")) : 0); v < 22; ++v) {
+    // divisors of the plane count near 8 / 32 / 128 planes per run (64 KiB / 256 KiB / 1 MiB of every destination row)
+    unsigned runs[3] = {1, 1, 1};
+    {
+      const unsigned want[3] = {8, 32, 128};
+      for (int t = 0; t < 3; ++t) {
+        unsigned best = 1;
+        for (unsigned d = 1; d <= (unsigned)c.s.ek; ++d)
+          if (c.s.ek % d == 0 && (best == 1 || (d > best ? d - want[t] : want[t] - d) < (best > want[t] ? best - want[t] : want[t] - best)) && d <= 4 * want[t]) best = d;
+        runs[t] = best;
+      }
+      printf("  (runs over planes: %u / %u / %u)\n", runs[0], runs[1], runs[2]);
+    }
+    for (int v = (getenv("TUNE_FROM") ? atoi(getenv("TUNE_FROM")) : 0); v < 25; ++v) {
+      if (getenv("TUNE_FROM") && v != 0 && v != 10 && v != 11 && v < 22) continue;
       Ctx x{src, dst, c.s, v, {}};
+      x.runs[0] = runs[0]; x.runs[1] = runs[1]; x.runs[2] = runs[2];
       CK(hipMemset(dst, 0, n * 8));
       const float ms = timeIt(run, &x);
       CK(hipMemset(bad, 0, 8));
