@@ -569,8 +569,47 @@ def emit(record):
     os.write(_RESULT_FD[0], (json.dumps(record) + "\n").encode())
 
 
+def launcher_command(argv, gpus, port):
+    """`python bench.py --gpus N` without a launcher around it: the command that runs it the way the driver does -- one rank
+    per GPU under torch.distributed.run on this node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """Called as a plain command with --gpus N > 1 (no RANK / WORLD_SIZE in the environment): start the N ranks ourselves and
+    hand their ONE JSON line through.  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launcher_command(sys.argv[1:], args.gpus, port)
+    sys.stderr.write("bench.py: --gpus %d without a launcher: running %s\n" % (args.gpus, " ".join(cmd)))
+    limit = (args.watchdog + 300) if args.watchdog > 0 else None
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=limit)
+    except subprocess.TimeoutExpired as e:
+        sys.stderr.write("bench.py: the launched ranks did not finish within %d s\n" % limit)
+        out, rc = (e.stdout or b""), 3
+    else:
+        out, rc = r.stdout, r.returncode
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+        return 0 if rc == 0 else rc
+    return rc or 3
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     sys.stdout.flush()
     _RESULT_FD[0] = os.dup(1)
     os.dup2(2, 1)

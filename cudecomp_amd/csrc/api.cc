@@ -448,6 +448,11 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->slot_used.assign(256, false);
     h->slot_high.assign(256, 0);
     h->tuning.no_streaming = envIsOne("CUDECOMP_DISABLE_STREAMING_ACCESS");
+    // A transpose normally never touches the halo / padding cells of its OUTPUT pencil (reference transpose.h:830-895).  Two
+    // kernels here read the few cells between consecutive output rows and write them back unchanged to write whole cache
+    // lines (rows_dense_kernel, transpose_lines_kernel): a caller who writes those cells on another stream WHILE the
+    // transpose runs opts out with this switch.
+    if (envIsOne("CUDECOMP_PRESERVE_OUTPUT_HALOS")) h->tuning.dense_rows = 0;
     // Tuning switches (kernel variants, walk orders, diagnostic store policies): read by `make TUNING_VARIANTS=1` builds only
     // (cudecomp_amd/lib_tuning); the default build has neither the variants nor the switches and says so once.
     auto tuningSwitch = [&](const char* var, int* out) {
@@ -458,7 +463,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
 #else
       (void)out;
       if (h->rank == 0)
-        printf("CUDECOMP:WARN: %s is a tuning switch of `make TUNING_VARIANTS=1` builds of this library; ignored.\n", var);
+        fprintf(stderr, "CUDECOMP:WARN: %s is a tuning switch of `make TUNING_VARIANTS=1` builds of this library; ignored.\n", var);
 #endif
     };
     tuningSwitch("CUDECOMP_INTERLEAVE_ROWS", &h->tuning.interleave_rows);
@@ -466,6 +471,9 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     tuningSwitch("CUDECOMP_WINDOW_WIDE", &h->tuning.window_wide);
     tuningSwitch("CUDECOMP_TILE_WALK", &h->tuning.walk_order);
     tuningSwitch("CUDECOMP_TILE_SHAPE", &h->tuning.tile_shape);
+    tuningSwitch("CUDECOMP_LINES_MODE", &h->tuning.lines_mode);
+    tuningSwitch("CUDECOMP_LINES_UNIT", &h->tuning.lines_unit);
+    tuningSwitch("CUDECOMP_LINES_RUN_KIB", &h->tuning.lines_run_kib);
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))
       if (std::strtol(v, nullptr, 10) == 1) h->tuning.force_class = MOVE_GENERIC;
 

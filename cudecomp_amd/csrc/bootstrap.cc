@@ -322,6 +322,7 @@ class Hub {
 
 struct TcpShared {
   int fd = -1;
+  int instances = 0;         // bootstraps created on THIS hub connection so far
   std::unique_ptr<Hub> hub;  // rank 0 only
   ~TcpShared() {
     if (fd >= 0) ::close(fd);
@@ -446,7 +447,11 @@ std::unique_ptr<Bootstrap> makeTcpBootstrap(const LaunchEnv& env, int instance) 
     sendAll(sh->fd, &hello, sizeof(hello));
     g_shared = sh;
   }
-  auto b = std::make_unique<TcpBootstrap>(sh, mix(0xC0DEC0DEULL, (uint64_t)instance), env.rank, env.size);
+  // The communicator id counts the bootstraps of this hub CONNECTION, not of the process: when the last handle is finalized
+  // the connection goes away, and a process that later joins another job (a long-lived worker that serves several launches,
+  // tests/mp.py) starts from zero like the fresh processes it meets there.
+  (void)instance;
+  auto b = std::make_unique<TcpBootstrap>(sh, mix(0xC0DEC0DEULL, (uint64_t)sh->instances++), env.rank, env.size);
   b->barrier();  // everyone is connected and agrees on the instance number
   return b;
 }

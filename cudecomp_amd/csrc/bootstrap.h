@@ -55,7 +55,7 @@ std::unique_ptr<Bootstrap> makeLocalBootstrap();
 // default build: control plane over the MPICH-ABI MPI the calling program brought with it (bootstrap_dynmpi.cc);
 // nullptr if there is none
 std::unique_ptr<Bootstrap> makeDynMpiBootstrap(int comm);
-// instance: n-th bootstrap created by this process (all ranks create them in the same order)
+// instance: n-th bootstrap created by this process (informational; the communicator id counts per hub connection, bootstrap.cc)
 std::unique_ptr<Bootstrap> makeTcpBootstrap(const LaunchEnv& env, int instance);
 
 }  // namespace cudecomp

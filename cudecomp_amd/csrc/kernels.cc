@@ -34,6 +34,8 @@ struct Classified {
   bool swizzle = false;  // transposes: XOR-swizzled LDS tile (else padded rows)
   bool window = false;   // transposes: destination rows off the 64-byte grid -> transpose_window_kernel (rows: rows_shifted_kernel)
   bool dense = false;    // rows, with window: whole lines across the row ends (rows_dense_kernel)
+  bool lines = false;    // transposes, with window: windows over the linear positions of adjacent rows (transpose_lines_kernel)
+  int unit = 0;          // ... and its alignment unit in bytes
   unsigned int t0, t1;
   unsigned long long blocks;
   i64 elements;
@@ -250,6 +252,33 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
     }
     if (j_first) c.p1 |= 2;
     c.blocks = (unsigned long long)c.t0 * c.t1 * (unsigned long long)c.dm.e[2];
+    // Destination rows off the 64-byte grid AND the rows of consecutive batch planes adjacent in memory (forward hops of an
+    // axis-contiguous cycle onto a halo-carrying pencil): every row begins and ends inside a cache line whose other part
+    // belongs to the next plane -- for the window kernel another workgroup, much later; the partly written lines cost the
+    // forward hops a sixth of their rate (0.60 against 0.72 of the HBM peak, profiles/r05_tuning.md section 3).  When the
+    // planner says the move covers whole interior rows of the pencil (dst_row_pitch: the gap cells are then halo / padding
+    // cells nobody else writes during the operation, the contract of rows_dense_kernel) j and k are fused into the slab's
+    // linear positions and the windows run ACROSS the row ends (transpose_lines_kernel, kernels_lines.hip).
+    if (c.window && !wide && in.dst_row_pitch > 0 && !remote && (!tuning || (tuning->dense_rows != 0 && tuning->lines_mode != 0))) {
+      i64 planned_row = -1;
+      for (int i = 0; i < 3; ++i)
+        if (in.ds[i] == 1 && in.extent[i] > 1) planned_row = in.extent[i];
+      const int ub = linesUnitBytes(tuning ? tuning->lines_unit : 128);
+      const long long ej = c.dm.e[1], ek = c.dm.e[2], dk = c.dm.ds[2], gap = dk - ej;
+      const long long span = (ek - 1) * dk + ej;
+      if (ek > 1 && planned_row == ej && dk == in.dst_row_pitch && gap > 0 && gap * es <= kDenseMaxGapBytes && gap * 8 <= ej &&
+          c.dm.ds[0] >= span && span < (1ll << 30) && c.dm.e[0] < (1ll << 30) && dk >= tj + ub / es) {
+        c.lines = true;
+        c.unit = ub;
+        // 16-byte lanes need whole vectors along i only: the windows run over linear positions, whatever the row length
+        c.variant = (es < 16 && c.dm.e[0] % (16 / es) == 0) ? 16 / es : 1;
+        c.t1 = (unsigned int)((span + ub / es - 1 + tj - 1) / tj);  // windows along the linear positions (+ one unit of phase slack)
+        const long long run = std::max<long long>(1, ((long long)(tuning ? tuning->lines_run_kib : 256) << 10) / ((long long)tj * es));
+        c.p0 = (long long)c.t1 >= 2 * run ? (int)run : 0;
+        c.p1 = 1 | 2 | 8;  // XCD-contiguous, along the destination first, "lines"
+        c.blocks = (unsigned long long)c.t0 * c.t1;
+      }
+    }
     return c;
   }
 
@@ -283,14 +312,19 @@ void tileOf(int es, int variant, bool window, int* ti, int* tj) {
   }
 }
 
-void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bool window, bool dense, int es, const Batch& b,
-                 unsigned int blocks, hipStream_t stream) {
+void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bool window, bool dense, int lines_unit, int es,
+                 const Batch& b, unsigned int blocks, hipStream_t stream) {
   // what ran last, in the words of the kernel templates (bench.py reports its dominant kernel from here)
   int ti = 0, tj = 0;
   tileOf(es, variant, window, &ti, &tj);
-  if (cls == MOVE_ROWS_VEC)
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d>", dense ? "rows_dense_kernel" : (window ? "rows_shifted_kernel" : "rows_kernel"),
+  if (cls == MOVE_ROWS_VEC && dense)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "rows_dense_kernel<%d>", stream_access >= 1 ? 1 : 0);
+  else if (cls == MOVE_ROWS_VEC)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d>", window ? "rows_shifted_kernel" : "rows_kernel",
              variant, stream_access == 3 ? 3 : (stream_access >= 1 ? 1 : 0));
+  else if (cls == MOVE_TRANSPOSE && lines_unit)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_lines_kernel<%d,%d,%d,%d,%d,%d>", es, variant % 100, ti, tj,
+             (stream_access == 2 || stream_access == 4) ? 4 : 0, lines_unit);
   else if (cls == MOVE_TRANSPOSE && window)
     snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_window_kernel<%d,%d,%d,%d,%d>", es, variant % 100, ti, tj,
              (stream_access == 2 || stream_access == 4) ? 4 : stream_access);
@@ -304,7 +338,8 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
       launchRowsBatch(dense ? 2 : (window ? 1 : 0), variant, stream_access, b, blocks, stream);
       break;
     case MOVE_TRANSPOSE:
-      if (window) launchWindowBatch(es, variant % 100, variant >= 100, stream_access, b, blocks, stream);
+      if (lines_unit) launchLinesBatch(es, variant % 100, stream_access, lines_unit, b, blocks, stream);
+      else if (window) launchWindowBatch(es, variant % 100, variant >= 100, stream_access, b, blocks, stream);
       else if (es == 4) launchTransposeBatch4(variant, stream_access, swizzle, b, blocks, stream);
       else if (es == 8) launchTransposeBatch8(variant, stream_access, swizzle, b, blocks, stream);
       else launchTransposeBatch16(variant, stream_access, swizzle, b, blocks, stream);
@@ -351,7 +386,8 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
     unsigned long long blocks = 0;
     for (size_t j = i; j < cs.size() && b.n < kMaxBatch; ++j) {
       if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant || cs[j].stream != cs[i].stream ||
-          cs[j].swizzle != cs[i].swizzle || cs[j].window != cs[i].window || cs[j].dense != cs[i].dense)
+          cs[j].swizzle != cs[i].swizzle || cs[j].window != cs[i].window || cs[j].dense != cs[i].dense ||
+          cs[j].lines != cs[i].lines || cs[j].unit != cs[i].unit)
         continue;
       if (blocks + cs[j].blocks > 0x7fffffffULL) {
         if (b.n == 0) CD_NOT_SUPPORTED("single block move too large for one launch");
@@ -382,7 +418,8 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
         blocks = widest * b.n;
       }
     }
-    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, cs[i].swizzle, cs[i].window, cs[i].dense, es, b, (unsigned int)blocks, stream);
+    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, cs[i].swizzle, cs[i].window, cs[i].dense, cs[i].lines ? cs[i].unit : 0, es, b,
+                (unsigned int)blocks, stream);
     if (stats) stats->launches[cs[i].cls] += 1;
   }
 }

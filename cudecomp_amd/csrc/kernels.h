@@ -26,7 +26,13 @@ struct KernelTuning {
   // tuning switches (read from the environment by `make TUNING_VARIANTS=1` builds only, csrc/api.cc):
   int walk_order = -1;           // transposes walk tiles i first (0) / j first (1); -1 = by strides (CUDECOMP_TILE_WALK)
   int interleave_rows = 1;       // batched row copies: workgroups serve the moves round robin (0: one move after the other)
-  int dense_rows = -1;           // row copies of whole rows onto halo-carrying pencils: 0 = never the dense walk (tests: the shifted kernel instead)
+  int dense_rows = -1;           // moves of whole rows onto halo-carrying pencils: 0 = never rewrite the halo / padding cells between
+                                 // consecutive rows (no rows_dense_kernel, no transpose_lines_kernel: the shifted / window kernels
+                                 // instead); CUDECOMP_PRESERVE_OUTPUT_HALOS=1 in every build
+  int lines_mode = -1;           // permutations onto halo-carrying pencils whose consecutive batch planes are adjacent rows:
+                                 // -1 transpose_lines_kernel when it applies, 0 never (CUDECOMP_LINES_MODE, tuning builds)
+  int lines_unit = 128;          // its alignment unit in bytes (64: tuning builds only, CUDECOMP_LINES_UNIT)
+  int lines_run_kib = 256;       // its tile walk: KiB of every destination slab written before the next tile row (CUDECOMP_LINES_RUN_KIB)
   int window_mode = -1;          // transposes onto rows off the 64-byte grid: -1 window kernel for moves >= 1 MiB, 0 never, 1 always
   int window_wide = 0;           // window kernel, 8-byte elements: 1 = 128 x 64 tiles with 512 threads (CUDECOMP_WINDOW_WIDE=1)
   int tile_shape = -1;           // 4-byte transposes with 16-byte lanes: 64 x 128 tiles (2, the default), 64 x 64 (0) or 128 x 64 (1);
@@ -41,7 +47,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
 
 // How a move WOULD run (no launch, no device needed): class, kernel variant, tile, tile counts, walk parameters, access mode.
 // out[10] = {class, variant, tile_i (row copies: 0 plain / 1 shifted / 2 dense kernel), tile_j, tiles_i, tiles_j, batch, p0 (run length), p1 (walk bits: 1 XCD-contiguous, 2 j first,
-// 4 runs over batch planes), access mode}.  (Tests of the planning logic: tests/test_kernel_plan.py.)
+// 4 runs over batch planes, 8 transpose_lines_kernel), access mode}.  (Tests of the planning logic: tests/test_kernel_plan.py.)
 void describeMove(const Move3D& m, const void* src, void* dst, int es, const KernelTuning* tuning, long long out[10]);
 
 // name (template spelling) of the data-movement kernel launched last by this process, "" before the first launch

@@ -55,5 +55,8 @@ void launchTransposeBatch4(int variant, int stream_access, bool swizzle, const k
 void launchTransposeBatch8(int variant, int stream_access, bool swizzle, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
 void launchTransposeBatch16(int variant, int stream_access, bool swizzle, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
 void launchWindowBatch(int es, int variant, bool wide, int stream_access, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
+// kernels_lines.hip: windows over the destination's linear positions across row ends (unit_bytes: 128; 64 in tuning builds)
+void launchLinesBatch(int es, int variant, int stream_access, int unit_bytes, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
+int linesUnitBytes(int unit_choice);  // the unit the build really has for a wish
 
 }  // namespace cudecomp

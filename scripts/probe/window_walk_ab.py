@@ -13,7 +13,8 @@ def main():
     torch.cuda.set_device(0)
     h = cd.cudecompInit()
     st = torch.cuda.current_stream().cuda_stream
-    out = {"walk": os.environ.get("CUDECOMP_TILE_WALK", "default"), "cases": {}}
+    out = {"walk": os.environ.get("CUDECOMP_TILE_WALK", "default"), "cases": {},
+           "switches": {k: v for k, v in os.environ.items() if k.startswith("CUDECOMP_LINES") or k == "CUDECOMP_PRESERVE_OUTPUT_HALOS"}}
     for name, gdims, halo in (("1024^3 halo 1", (1024, 1024, 1024), (1, 1, 1)), ("2048x1024x256 halo 2", (2048, 1024, 256), (2, 2, 2))):
         gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims, (1, 1), axis_contiguous=(1, 1, 1)))
         nel = max(cd.cudecompGetPencilInfo(h, gd, ax, halo).size for ax in range(3))

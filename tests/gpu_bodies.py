@@ -20,11 +20,33 @@ def _handle(rank):
     """One library handle per process, shared by every case the process runs."""
     global _HANDLE
     if _HANDLE is None:
-        ndev = torch.cuda.device_count()
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(ndev, 1))
-        torch.zeros(1, device="cuda")  # create the context before the library probes the device
+        if torch.cuda.is_available():  # (tests/test_rank_pool.py drives the geometry queries through here on the CPU)
+            ndev = torch.cuda.device_count()
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(ndev, 1))
+            torch.zeros(1, device="cuda")  # create the context before the library probes the device
         _HANDLE = cd.cudecompInit()
     return _HANDLE
+
+
+def pool_probe(rank, nranks, args):
+    """What a rank of tests/mp.py's pool looks like from inside: process id, the launcher variables of THIS job, selected
+    switches, and -- through a library handle over the job's world -- every rank's pencil shape (geometry only: runs without
+    a GPU).  args: {"raise_on": rank that fails, "sleep": seconds, "handle": bool}."""
+    import time
+    out = {"pid": os.getpid(), "rank": rank, "nranks": nranks, "env_rank": os.environ.get("RANK"),
+           "world_size": os.environ.get("WORLD_SIZE"), "switch": os.environ.get(args.get("switch", "CUDECOMP_TEST_SWITCH")),
+           "pool": os.environ.get("CUDECOMP_TEST_RANK_POOL")}
+    if args.get("raise_on") == rank:
+        raise RuntimeError("pool_probe: rank %d fails on purpose" % rank)
+    if args.get("sleep"):
+        time.sleep(args["sleep"])
+    if args.get("handle", True):
+        h = _handle(rank)
+        gd = cd.cudecompGridDescCreate(h, cd.make_config(args.get("gdims", (12, 10, 14)), args.get("pdims", (nranks, 1))))
+        out["shape"] = list(cd.cudecompGetPencilInfo(h, gd, 1).shape)
+        out["handle_id"] = id(h) if not isinstance(h, int) else h
+        cd.cudecompGridDescDestroy(h, gd)
+    return out
 
 
 def _setup(rank, nranks, args):

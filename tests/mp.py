@@ -104,7 +104,215 @@ def shared_device_env(nranks, env):
         env.setdefault("GPU_MAX_HW_QUEUES", want)
 
 
-def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_rank_env=None):
+# ---- the rank pool -----------------------------------------------------------------------------------------------------
+# A launch of N fresh rank processes costs ~10 s before the first library call (N Python start-ups, N torch imports, N GPU
+# contexts); the GPU suite makes hundreds of launches, and that start-up was two thirds of its wall time (round 5: the driver's
+# run was cut at its limit).  GPU bodies therefore run on a POOL of long-lived rank workers: worker r imports everything and
+# opens the GPU once and then serves rank r of every job.  What a job may still change per launch -- world size, the
+# CUDECOMP_* switches the library reads when a handle is created -- is applied by finalizing the workers' handle and
+# creating a new one (collective, driven from here); what only a fresh process can change (a preloaded RCCL stand-in,
+# runtime-level variables) is part of the pool's signature: a job with another signature replaces the pool.  One failure or
+# timeout kills the whole pool (the next job starts a new one), so a wedged rank never leaks into later tests.
+# Never pooled: CPU bodies (gloo), per-rank environments, and the bodies in FRESH_FUNCS, which are ABOUT process-level state.
+POOL_SWITCH = "CUDECOMP_TEST_RANK_POOL"   # =0: every launch in fresh processes, as before round 6
+FRESH_FUNCS = {"absent_peer", "queue_census", "pool_pressure", "pool_behaviour", "malloc_timing", "link_info", "perf_report"}
+# extra_env keys that only matter when a HANDLE is created or later (read through getenv by libcudecomp.so at those points)
+_HANDLE_LEVEL_PREFIX = "CUDECOMP_"
+_PROCESS_LEVEL = {"CUDECOMP_TEST_RCCL_SHIM", "CUDECOMP_AMD_LIBRARY", "CUDECOMP_DISABLE_MPI_DISCOVERY"}
+
+
+def _split_env(extra_env):
+    proc, handle = {}, {}
+    for k, v in (extra_env or {}).items():
+        if k.startswith(_HANDLE_LEVEL_PREFIX) and k not in _PROCESS_LEVEL:
+            handle[k] = str(v)
+        else:
+            proc[k] = str(v)
+    return proc, handle
+
+
+class _Pool:
+    def __init__(self, proc_env):
+        self.proc_env = dict(proc_env)
+        self.workers = []   # (Popen, read end of the answer pipe, log path)
+        self.buf = []       # bytes of a worker's answers not consumed yet
+        self.world = None   # (nranks, handle-env items) of the handle the workers 0..nranks-1 hold
+        self.ports = None
+        self.dir = tempfile.mkdtemp(prefix="cudecomp_pool_")
+        self.seq = 0
+        self.jobs = 0
+
+    def grow(self, n):
+        import select
+        first = len(self.workers)
+        for r in range(first, n):
+            env = dict(os.environ)
+            env.update({"LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                        "PYTHONPATH": ROOT + os.pathsep + env.get("PYTHONPATH", "")})
+            env.setdefault("CUDECOMP_PIPELINE_MIN_STAGE_MIB", "0")
+            env[POOL_SWITCH] = "0"  # a worker never starts a pool of its own
+            shared_device_env(8, env)
+            env.update(self.proc_env)
+            rfd, wfd = os.pipe()
+            log = os.path.join(self.dir, "worker%d.log" % r)
+            with open(log, "wb") as lf:
+                p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(r), str(wfd)], env=env, cwd=ROOT,
+                                     stdin=subprocess.PIPE, stdout=lf, stderr=subprocess.STDOUT, pass_fds=(wfd,))
+            os.close(wfd)
+            self.workers.append((p, rfd, log))
+            self.buf.append(b"")
+        for r in range(first, n):  # wait until every new worker has its GPU context (first import of torch: up to minutes)
+            if self._read(r, 600) is None:
+                raise AssertionError("pool worker %d did not come up\n%s" % (r, self._log_tail(r, 0)))
+
+    def _read(self, r, timeout):
+        """Next answer line of worker r as an object; None on timeout or when the worker is gone."""
+        import select
+        import time
+        p, rfd, _ = self.workers[r]
+        deadline = time.monotonic() + timeout
+        while b"\n" not in self.buf[r]:
+            ready, _, _ = select.select([rfd], [], [], max(0.0, deadline - time.monotonic()))
+            if not ready:
+                return None
+            chunk = os.read(rfd, 65536)
+            if not chunk:
+                return None
+            self.buf[r] += chunk
+        line, self.buf[r] = self.buf[r].split(b"\n", 1)
+        return json.loads(line)
+
+    def _log_tail(self, r, start):
+        try:
+            with open(self.workers[r][2], "rb") as f:
+                f.seek(start)
+                return f.read().decode(errors="replace")[-4000:]
+        except OSError:
+            return ""
+
+    def _send(self, r, msg):
+        p = self.workers[r][0]
+        p.stdin.write((json.dumps(msg) + "\n").encode())
+        p.stdin.flush()
+
+    def _finalize_world(self):
+        if self.world is None:
+            return True
+        n = self.world[0]
+        self.seq += 1
+        for r in range(n):
+            self._send(r, {"cmd": "finalize", "id": self.seq})
+        ok = True
+        for r in range(n):
+            ans = self._read(r, 120)
+            ok = ok and ans is not None and ans.get("ok")
+        self.world = None
+        return ok
+
+    def run(self, nranks, module, func, args, timeout, handle_env):
+        import time
+        if len(self.workers) < nranks:
+            self.grow(nranks)
+        world = (nranks, tuple(sorted(handle_env.items())))
+        if self.world != world:
+            if not self._finalize_world():
+                raise AssertionError("pool: finalizing the previous world failed")
+            self.ports = (free_port(), free_port())
+            self.world = world
+        self.seq += 1
+        self.jobs += 1
+        outs, starts = [], []
+        for r in range(nranks):
+            out = os.path.join(self.dir, "job%d_rank%d.json" % (self.seq, r))
+            outs.append(out)
+            try:
+                starts.append(os.path.getsize(self.workers[r][2]))
+            except OSError:
+                starts.append(0)
+            env = {"RANK": str(r), "WORLD_SIZE": str(nranks), "LOCAL_RANK": str(r), "MASTER_PORT": str(self.ports[0]),
+                   "CUDECOMP_BOOTSTRAP_PORT": str(self.ports[1])}
+            env.update(handle_env)
+            self._send(r, {"cmd": "job", "id": self.seq, "module": module, "func": func, "args": args or {}, "env": env, "out": out})
+        deadline = time.monotonic() + timeout
+        results, failures = [], []
+        for r in range(nranks):
+            ans = self._read(r, max(0.0, deadline - time.monotonic()))
+            if ans is None:
+                failures.append("rank %d timed out or died\n%s" % (r, self._log_tail(r, starts[r])))
+            elif not ans.get("ok") or not os.path.exists(outs[r]):
+                failures.append("rank %d failed\n%s" % (r, self._log_tail(r, starts[r])))
+            else:
+                with open(outs[r]) as f:
+                    results.append(json.load(f))
+                os.unlink(outs[r])
+        if failures:
+            raise AssertionError("\n".join(failures))
+        return results
+
+    def stop(self, kill=False):
+        import shutil
+        if not kill:
+            for p, _, _ in self.workers:
+                try:
+                    p.stdin.close()   # EOF: finalize (collective among the members of the current world) and leave
+                except OSError:
+                    pass
+            for p, _, _ in self.workers:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    kill = True
+        for p, rx, _ in self.workers:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+            try:
+                os.close(rx)
+            except OSError:
+                pass
+        self.workers, self.buf = [], []
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
+_pool = [None]
+pool_stats = {"started": 0, "jobs": 0, "fresh_launches": 0}
+
+
+def pool_stop(kill=False):
+    """Ends the rank pool, if one is alive (before anything else puts processes on the GPU: a forked in-process child, native
+    test programs, fresh rank launches -- nine processes with a GPU context are one more than the device serves without
+    time-slicing them)."""
+    if _pool[0] is not None:
+        pool, _pool[0] = _pool[0], None
+        pool_stats["jobs"] += pool.jobs
+        pool.stop(kill)
+
+
+def _pool_run(nranks, module, func, args, timeout, extra_env):
+    proc_env, handle_env = _split_env(extra_env)
+    if _pool[0] is not None and _pool[0].proc_env != proc_env:
+        pool_stop()
+    if _pool[0] is None:
+        import atexit
+        _pool[0] = _Pool(proc_env)
+        pool_stats["started"] += 1
+        if pool_stats["started"] == 1:
+            atexit.register(pool_stop, True)
+    try:
+        return _pool[0].run(nranks, module, func, args, timeout, handle_env)
+    except BaseException:
+        pool_stop(kill=True)  # whatever state the ranks are in, the next job starts from fresh processes
+        raise
+
+
+def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_rank_env=None, fresh=None):
+    if fresh is None:
+        fresh = (os.environ.get(POOL_SWITCH, "1") == "0" or module != "tests.gpu_bodies" or func in FRESH_FUNCS or
+                 per_rank_env is not None or nranks > 8)
+    if not fresh:
+        return _pool_run(nranks, module, func, args, timeout, extra_env)
+    pool_stop()
+    pool_stats["fresh_launches"] += 1
     port_a, port_b = free_port(), free_port()
     outdir = tempfile.mkdtemp(prefix="cudecomp_mp_")
     procs = []
@@ -146,15 +354,90 @@ def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_
     return results
 
 
-if __name__ == "__main__":
-    import importlib
-    module, func, args, out = sys.argv[1:5]
+def _load_shim_first():
     if os.environ.get("CUDECOMP_TEST_RCCL_SHIM"):
         # tests/shim: make the stand-in's nccl* symbols global BEFORE libcudecomp.so is loaded, after torch so that
         # its HIP dependency binds to the runtime already in the process (same order rule as cudecomp_amd.lib())
         import ctypes
         import torch  # noqa: F401
         ctypes.CDLL(os.environ["CUDECOMP_TEST_RCCL_SHIM"], mode=ctypes.RTLD_GLOBAL)
+
+
+def _worker_main(index, result_fd):
+    """A long-lived rank of the pool (see _Pool): imports torch and the library ONCE, opens the GPU once, then serves
+    jobs from stdin -- one JSON object per line -- and answers on `result_fd`.  Commands: {"cmd": "job", ...},
+    {"cmd": "finalize"} (collective: every member of the current world gets it), EOF = finalize and leave."""
+    import gc
+    import importlib
+    import traceback
+    res = os.fdopen(result_fd, "w", buffering=1)
+    _load_shim_first()
+    import torch
+    from tests import gpu_bodies as B
+    import cudecomp_amd as cd
+    if torch.cuda.is_available():  # (the pool's own CPU tests run the protocol without a GPU)
+        torch.cuda.set_device(index % max(torch.cuda.device_count(), 1))
+        torch.zeros(1, device="cuda")
+    res.write(json.dumps({"ready": index}) + "\n")
+
+    def finalize():
+        if B._HANDLE is not None:
+            h, B._HANDLE = B._HANDLE, None
+            cd.cudecompFinalize(h)
+
+    for line in sys.stdin:
+        msg = json.loads(line)
+        if msg["cmd"] == "finalize":
+            try:
+                finalize()
+                res.write(json.dumps({"id": msg["id"], "ok": True}) + "\n")
+            except Exception:  # noqa: BLE001
+                traceback.print_exc()
+                res.write(json.dumps({"id": msg["id"], "ok": False}) + "\n")
+            continue
+        saved = {}
+        for k, v in msg["env"].items():
+            saved[k] = os.environ.get(k)
+            os.environ[k] = v
+        ok = True
+        try:
+            print("=== job %s: %s.%s rank %s of %s" % (msg["id"], msg["module"], msg["func"], msg["env"]["RANK"], msg["env"]["WORLD_SIZE"]), flush=True)
+            fn = getattr(importlib.import_module(msg["module"]), msg["func"])
+            result = fn(int(msg["env"]["RANK"]), int(msg["env"]["WORLD_SIZE"]), msg["args"])
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            with open(msg["out"], "w") as f:
+                json.dump(result, f)
+        except BaseException:  # noqa: BLE001
+            traceback.print_exc()
+            ok = False
+        sys.stdout.flush()
+        sys.stderr.flush()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        gc.collect()
+        try:
+            if torch.cuda.is_available() and torch.cuda.memory_reserved() > (24 << 30):  # a full-size case: do not sit on its buffers while others run
+                torch.cuda.empty_cache()
+        except Exception:  # noqa: BLE001
+            pass
+        res.write(json.dumps({"id": msg["id"], "ok": ok}) + "\n")
+    try:
+        finalize()
+    except Exception:  # noqa: BLE001
+        pass
+
+
+if __name__ == "__main__":
+    import importlib
+    if sys.argv[1] == "--worker":
+        _worker_main(int(sys.argv[2]), int(sys.argv[3]))
+        sys.exit(0)
+    module, func, args, out = sys.argv[1:5]
+    _load_shim_first()
     rank, nranks = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     result = getattr(importlib.import_module(module), func)(rank, nranks, json.loads(args))
     with open(out, "w") as f:
@@ -165,6 +448,7 @@ def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
     """Launch a native executable (C / Fortran test twin) on N ranks with the same launcher environment;
     returns the list of per-rank stdout+stderr texts, raising on any non-zero exit."""
     import uuid
+    pool_stop()
     port_a, port_b = free_port(), free_port()
     job = uuid.uuid4().hex[:16]  # scratch-file namespace of this launch (tests/native, tests/fortran verdict files)
     procs = []

@@ -51,3 +51,32 @@ def test_cpu_baseline_record_has_the_required_fields():
         slots = rec["one_rank_per_gpu_slot"]  # one rank per GPU slot, config 3's 2x4 grid
         if slots is not None and "unavailable" not in slots:
             assert slots["ranks"] == 8 and slots["grid"] == [2, 4] and slots["round_trip_ok"] and slots["value"] > 0
+
+
+def test_gpus_n_as_a_plain_command_launches_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus 4 --steps 2 --warmup 1` with no launcher around it must behave like the driver's
+    torch.distributed.run line: N ranks on this node, rendezvous on 127.0.0.1, the ranks' ONE JSON line passed through."""
+    import subprocess
+    import types
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "2"], 4, 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511" and cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    seen = {}
+
+    def fake_run(c, env=None, stdout=None, timeout=None):
+        seen.update(cmd=c, env=env, timeout=timeout)
+        return types.SimpleNamespace(returncode=0, stdout=b'noise\n{"n_gpus": 4, "value": 1.0}\n')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    for k in ("RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    args = bench.parse()
+    assert bench.self_launch(args) == 0
+    assert capsys.readouterr().out.strip() == '{"n_gpus": 4, "value": 1.0}'
+    assert seen["cmd"][-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["timeout"] == args.watchdog + 300
+    # ranks that print nothing parseable: a non-zero exit code, no line
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout=b"nothing\n"))
+    assert bench.self_launch(args) != 0

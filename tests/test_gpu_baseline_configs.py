@@ -78,6 +78,7 @@ RCCL_PATH_CONFIGS = [c for c in CONFIGS if c[0].startswith("C2")] + [
     ("C3grid_512cube_f64_2x4", 8, {"gdims": (512, 512, 512), "pdims": (2, 4), "kind": 1})]
 
 
+@pytest.mark.suite_order(2)  # (the stand-in is preloaded: another rank pool -- after the module's other tests, next to test_gpu_rccl_path)
 @pytest.mark.parametrize("name,nranks,args", RCCL_PATH_CONFIGS, ids=[c[0] for c in RCCL_PATH_CONFIGS])
 @pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_NCCL, cd.TRANSPOSE_COMM_NCCL_PL], ids=["nccl", "nccl_pl"])
 def test_full_size_every_cell_rccl_code_path(name, nranks, args, backend):
@@ -107,7 +108,8 @@ def test_config3_autotuned_process_grid_at_full_size():
 
 @pytest.mark.parametrize("axes,backend,env", [([0, 1, 2], cd.HALO_COMM_MPI, {}),
                                               ([0, 1, 2], cd.HALO_COMM_NVSHMEM, {}),
-                                              ([0, 1, 2], cd.HALO_COMM_NCCL, {"CUDECOMP_FORCE_HALO_OVERLAP": "1"})],
+                                              pytest.param([0, 1, 2], cd.HALO_COMM_NCCL, {"CUDECOMP_FORCE_HALO_OVERLAP": "1"},
+                                                           marks=pytest.mark.suite_order(2))],
                          ids=["mpi_xyz", "nvshmem_xyz", "rccl_overlapped_xyz"])
 def test_config5_halo_full_size(axes, backend, env):
     # C5: 2048 x 2048 x 1024 fp64, 2x4, halo width 2, periodic: UpdateHalos{X,Y,Z} dims 0,1,2 with pack / exchange /

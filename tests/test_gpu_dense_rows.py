@@ -6,6 +6,8 @@ same seeded inputs, EVERY byte of the destination compared (so a gap cell that c
 span that is touched, fails).  API level: transposes onto halo-carrying / padded pencils (reference semantics:
 include/internal/transpose.h:830-895, the unpack copies; halo / padding cells are not the transpose's to change) on one
 rank and on 2 x 2 ranks sharing the GPU, every byte of the output buffers compared.  Bit-exact (tolerance 0)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -66,7 +68,7 @@ def test_dense_rows_large_moves_take_it_by_themselves():
     w, hgt, d, es = 1024, 768, 8, 8
     ds = [1, w + 2, (w + 2) * (hgt + 2)]
     dense_move(es, (w, hgt, d), [1, w, w * hgt], ds, w * hgt * d + 16, 1 + ds[1] + ds[2] * d + 16, 0, 1 + ds[1], seed=3, flags=WHOLE)
-    assert cd.cudecompExtLastKernelName() == "rows_dense_kernel<16,1>"
+    assert cd.cudecompExtLastKernelName() == "rows_dense_kernel<1>"
     # a plane of more than 4 GiB of span (row / offset arithmetic beyond 32 bits): one plane of 4.25 million rows of 1 KiB
     w, hgt, es = 256, 4250000, 4
     ds = [1, w + 2, 0]
@@ -128,3 +130,130 @@ def test_transposes_onto_halo_pencils_every_byte_four_ranks(backend):
                               "transpose_backend": backend, "expect_kernel": expect}})
     for failures in run_ranks(4, "tests.gpu_bodies", "many", {"jobs": jobs}, timeout=600):
         assert failures == []
+
+
+# ---- permutations onto halo-carrying pencils whose consecutive batch planes are adjacent rows: transpose_lines_kernel ----------
+LINES = "transpose_lines_kernel"
+
+
+def lines_move(es, ei, ej, ek, gap, extra_rows, slab_pad, spad, doff, seed, flags, expect_lines=True):
+    """dst[doff + i*di + k*dk + j] = src[i + j*sj + k*sk]: source rows along i (pitch ei + spad), destination rows along j of
+    pitch dk = ej + gap, consecutive k adjacent, slabs di = dk * (ek + extra_rows) + slab_pad apart; every byte compared."""
+    sj = ei + spad
+    sk = sj * ej
+    dk = ej + gap
+    di = dk * (ek + extra_rows) + slab_pad
+    extent, ss, ds = (ei, ej, ek), (1, sj, sk), (di, 1, dk)
+    src = G.random_payload(sk * ek + 64, es, seed)
+    dst0 = G.random_payload(doff + di * ei + 64, es, seed + 1)
+    exp = dst0.copy()
+    orc.move3d_reference(src, exp, extent, ss, ds, 0, doff)
+    d_src, d_dst = G.to_device(src.view(np.uint8)), G.to_device(dst0.view(np.uint8))
+    cls = cd.cudecompExtMove3D(d_src.data_ptr(), d_dst.data_ptr() + doff * es, es, extent, ss, ds, flags, G.stream_ptr())
+    torch.cuda.synchronize()
+    name = cd.cudecompExtLastKernelName()
+    got = G.to_host(d_dst)
+    assert cls == 1, (cls, name)
+    assert name.startswith(LINES) == expect_lines, (name, es, extent, ss, ds, flags)
+    assert np.array_equal(got, exp.view(np.uint8)), (name, es, extent, ss, ds, doff, flags,
+                                                    np.nonzero(got != exp.view(np.uint8))[0][:8] // es)
+
+
+@pytest.mark.parametrize("es", [4, 8, 16])
+def test_lines_kernel_move_by_move(es):
+    # (ei, ej, ek, gap, extra rows per slab, slab padding, source row padding, dst offset): edge tiles along i and along the
+    # linear positions, odd plane counts, one and several row ends per window, slabs whose phase differs from slab to slab
+    shapes = [(64, 256, 3, 2, 2, 0, 0, 1), (70, 300, 5, 2, 0, 1, 0, 1), (128, 200, 7, 1, 1, 3, 2, 0), (33, 1026, 2, 4, 2, 0, 0, 5),
+              (200, 160, 9, 6, 0, 0, 1, 3), (96, 513, 4, 3, 1, 7, 0, 2), (64, 2050, 2, 2, 2, 0, 0, 2), (130, 384, 11, 8, 0, 5, 3, 7)]
+    for ei, ej, ek, gap, xr, sp, spad, doff in shapes:
+        if gap * 8 > ej:
+            continue
+        for flags in (WHOLE | ALWAYS, WHOLE | ALWAYS | STREAMING):
+            lines_move(es, ei, ej, ek, gap, xr, sp, spad, doff, seed=ei + ej + ek, flags=flags)
+        # without the planner's word the gap cells are not the move's: the window kernel, same result
+        lines_move(es, ei, ej, ek, gap, xr, sp, spad, doff, seed=ej, flags=ALWAYS, expect_lines=False)
+
+
+def test_lines_kernel_large_moves_take_it_by_themselves():
+    # 1024-wide fp64 rows with a halo of one cell, 64 slabs x 48 planes = 24 MiB + a run walk with a ragged last run
+    lines_move(8, 64, 1024, 48, 2, 2, 0, 0, 1 + 1026, seed=5, flags=WHOLE)
+    assert cd.cudecompExtLastKernelName() == "transpose_lines_kernel<8,2,64,64,0,128>"
+    lines_move(8, 256, 2048, 36, 4, 4, 0, 0, 2 + 2 * 2052, seed=6, flags=WHOLE | STREAMING)
+    assert cd.cudecompExtLastKernelName() == "transpose_lines_kernel<8,2,64,64,4,128>"
+
+
+def test_lines_kernel_random_sweep():
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(es=st.sampled_from([4, 8, 16]), ei=st.integers(4, 200), ejq=st.integers(40, 700), ek=st.integers(2, 9),
+           gap=st.integers(1, 8), xr=st.integers(0, 3), sp=st.integers(0, 9), spad=st.integers(0, 3), doff=st.integers(0, 40),
+           stream=st.booleans(), seed=st.integers(0, 1 << 20))
+    def check(es, ei, ejq, ek, gap, xr, sp, spad, doff, stream, seed):
+        tj, u = {4: (128, 32), 8: (64, 16), 16: (32, 8)}[es]
+        ej = max(ejq, tj + u, 8 * gap)   # (rows at least one window + one unit long: at most one row end per tile)
+        dk, di = ej + gap, (ej + gap) * (ek + xr) + sp
+        aligned = (doff * es) % 64 == 0 and (dk * es) % 64 == 0 and (di * es) % 64 == 0
+        if aligned:
+            doff += 1
+        lines_move(es, ei, ej, ek, gap, xr, sp, spad, doff, seed, WHOLE | ALWAYS | (STREAMING if stream else 0))
+
+    check()
+
+
+def test_preserve_output_halos_switch_keeps_concurrent_halo_writes(tmp_path):
+    """CUDECOMP_PRESERVE_OUTPUT_HALOS=1: a transpose must then never touch the halo / padding cells of its output (the
+    reference's behaviour, include/internal/transpose.h:830-895), so a kernel of the caller that writes those cells on ANOTHER
+    stream while the transpose runs keeps its values.  Without the switch the whole-line kernels run (and are named), with it
+    the shifted / window kernels; both give the right interior."""
+    import json
+    import subprocess
+    import sys
+    from tests.mp import ROOT
+    code = r'''
+import json, os, sys
+import numpy as np, torch
+import cudecomp_amd as cd
+torch.cuda.set_device(0)
+h = cd.cudecompInit()
+out = {}
+for ac in ((0, 0, 0), (1, 1, 1)):
+    gdims, halo = (512, 256, 128), (1, 1, 1)
+    gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims, (1, 1), axis_contiguous=ac))
+    px, py = cd.cudecompGetPencilInfo(h, gd, 0, halo), cd.cudecompGetPencilInfo(h, gd, 1, halo)
+    a = torch.arange(px.size, dtype=torch.float64, device="cuda")
+    b = torch.full((py.size,), -5.0, dtype=torch.float64, device="cuda")
+    work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * 8)
+    # interior mask of the Y pencil (memory order of py): halo cells are everything else
+    shape = [py.shape[2], py.shape[1], py.shape[0]]
+    m = torch.zeros(shape, dtype=torch.bool, device="cuda")
+    m[1:-1, 1:-1, 1:-1] = True
+    m = m.reshape(-1)
+    side = torch.cuda.Stream()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    for rep in range(6):
+        cd.cudecompTranspose("XToY", h, gd, a.data_ptr(), b.data_ptr(), work, cd.DOUBLE, halo, halo, None, None, st)
+        with torch.cuda.stream(side):   # the caller's own halo fill, concurrently
+            b.masked_fill_(~m, 100.0 + rep)
+    torch.cuda.synchronize()
+    out[str(ac)] = {"kernel": cd.cudecompExtLastKernelName(), "halo_ok": bool((b[~m] == 105.0).all()),
+                    "interior_ok": bool((b[m] >= 0).all())}
+    cd.cudecompFree(h, gd, work); cd.cudecompGridDescDestroy(h, gd)
+cd.cudecompFinalize(h)
+print("RESULT " + json.dumps(out))
+'''
+    res = {}
+    for switch in ("0", "1"):
+        env = dict(os.environ, PYTHONPATH=ROOT, CUDECOMP_PRESERVE_OUTPUT_HALOS=switch)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[switch] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["0"]["(0, 0, 0)"]["kernel"].startswith("rows_dense_kernel"), res
+    assert res["0"]["(1, 1, 1)"]["kernel"].startswith(LINES), res
+    assert res["1"]["(0, 0, 0)"]["kernel"].startswith("rows_shifted_kernel"), res
+    assert res["1"]["(1, 1, 1)"]["kernel"].startswith("transpose_window_kernel"), res
+    for ac in ("(0, 0, 0)", "(1, 1, 1)"):
+        assert res["1"][ac]["halo_ok"] and res["1"][ac]["interior_ok"], res
+        assert res["0"][ac]["interior_ok"], res

@@ -197,3 +197,96 @@ def test_dense_walk_restatement_copies_rows_and_leaves_everything_else():
         assert np.array_equal(out, exp)
         span = (rows - 1) * pitch + row_bytes
         assert written[d0:d0 + span].all() and not written[:d0].any() and not written[d0 + span:].any()
+
+
+# ---- permutations onto halo-carrying pencils whose consecutive batch planes are adjacent rows: transpose_lines_kernel ----------
+LINES = 8  # walk bit of cudecompExtDescribeMove
+
+
+def lines_shape(nx, ny, nz, h, es=8, whole=True, dst_off=None):
+    """X->Y hop of an axis-contiguous 1 x 1 cycle onto a Y pencil with a halo of h cells on every axis: source x fastest
+    (dense), destination y fastest, rows of consecutive z planes adjacent, x slabs far apart."""
+    py, pz = ny + 2 * h, nz + 2 * h
+    off = h + py * (h + pz * h) if dst_off is None else dst_off
+    return cd.cudecompExtDescribeMove(SRC, DST + off * es, es, (nx, ny, nz), (1, nx, nx * ny), (py * pz, 1, py),
+                                      flags=WHOLE if whole else 0)
+
+
+def test_lines_kernel_is_chosen_for_forward_hops_onto_halo_pencils_only():
+    d = lines_shape(1024, 1024, 1022, 1)
+    assert d["cls"] == 1 and d["walk"] & LINES and (d["tile_i"], d["tile_j"], d["access"]) == (64, 64, 4), d
+    span = 1021 * 1026 + 1024
+    assert d["tiles_i"] == 16 and d["tiles_j"] == -(-(span + 15) // 64) and d["run"] * 64 * 8 == 256 << 10, d
+    c5 = lines_shape(2048, 2048, 256, 2)  # config 5's pencil shape on a 1 x 1 grid
+    assert c5["walk"] & LINES and c5["variant"] == 2, c5
+    for es in (4, 16):
+        assert lines_shape(1024, 1024, 64, 1, es=es)["walk"] & LINES
+    # without the planner's word the gap cells are not the move's: the window kernel
+    w = lines_shape(1024, 1024, 1022, 1, whole=False)
+    assert w["cls"] == 1 and not w["walk"] & LINES and w["access"] == 4, w
+    # line-aligned rows need neither kernel
+    a = cd.cudecompExtDescribeMove(SRC, DST, 8, (1024, 1024, 64), (1, 1024, 1 << 20), ((1024 + 16) * 64, 1, 1024 + 16), flags=WHOLE)
+    assert not a["walk"] & LINES and a["access"] == 2, a
+    # inverse hops (the tile's own rows are the adjacent ones, batch planes far apart) keep the window kernel
+    inv = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (1024, 1024, 64), (1, 1024 * 64, 1024), (1026, 1, 1026 * 1026), flags=WHOLE)
+    assert inv["cls"] == 1 and not inv["walk"] & LINES, inv
+    # wide gaps (a slab out of a wider pencil) are not rewritten
+    wide = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (1024, 1024, 64), (1, 1024, 1 << 20), (2048 * 70, 1, 2048), flags=WHOLE)
+    assert not wide["walk"] & LINES, wide
+    # small moves stay with the plain tile kernel unless asked (flag 4), like the window kernel
+    assert not lines_shape(128, 128, 4, 1)["walk"] & LINES
+    small = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (128, 128, 8), (1, 128, 128 * 128), (130 * 10, 1, 130), flags=WHOLE | 4)
+    assert small["walk"] & LINES and small["run"] == 0, small
+    # an odd row count along i: element-wise lanes (vectors hold whole elements along i only)
+    assert lines_shape(1023, 1024, 64, 1)["variant"] == 1
+    assert lines_shape(1024, 1023, 64, 1)["variant"] == 2   # the row length does not matter
+
+
+def lines_walk_reference(ei, ej, ek, di, dk, dst_phase, es, ti, tj, run, ub=128):
+    """numpy restatement of transpose_lines_kernel's decode: which (slab i, linear position l) every workgroup stores.
+    Returns the coverage count per (i, l) over [0, L) and the number of stores that would fall outside."""
+    U = ub // es
+    L = (ek - 1) * dk + ej
+    ti_n, tl_n = -(-ei // ti), -(-(L + U - 1) // tj)
+    cover = np.zeros((ei, L), dtype=np.int32)
+    outside = 0
+    nb = ti_n * tl_n
+    per = nb >> 3
+    seen = set()
+    for lb in range(nb):
+        lt = (lb & 7) * per + (lb >> 3) if lb < (per << 3) else lb
+        r = run if run > 0 else tl_n
+        full_runs = tl_n // r
+        full = full_runs * r * ti_n
+        if lt < full:
+            lo, rest = lt % r, lt // r
+            bi, bl = rest % ti_n, (rest // ti_n) * r + lo
+        else:
+            tail, x = tl_n - full_runs * r, lt - full
+            bl, bi = full_runs * r + x % tail, x // tail
+        assert (bi, bl) not in seen and bi < ti_n and bl < tl_n
+        seen.add((bi, bl))
+        lb0 = bl * tj - (U - 1)
+        for i in range(bi * ti, min(ei, bi * ti + ti)):
+            ph = (dst_phase + i * di) % U
+            lo_l = lb0 + (U - 1) - ph
+            assert (dst_phase + i * di + lo_l) % U == 0  # every window starts on a unit boundary
+            a, b = max(lo_l, 0), min(lo_l + tj, L)
+            if b > a:
+                cover[i, a:b] += 1
+    assert len(seen) == nb
+    return cover, outside
+
+
+def test_lines_walk_covers_every_cell_of_every_slab_exactly_once():
+    rng = random.Random(11)
+    for _ in range(60):
+        es = rng.choice([4, 8, 16])
+        ti, tj = {4: (64, 128), 8: (64, 64), 16: (32, 32)}[es]
+        ei, ej, ek = rng.choice([32, 64, 100, 130]), rng.choice([160, 200, 257, 300]), rng.choice([2, 3, 5, 9])
+        gap = rng.choice([1, 2, 3, 4, 6])
+        dk = ej + gap
+        di = dk * (ek + rng.choice([0, 1, 2])) + rng.choice([0, 1, 5])
+        run = rng.choice([0, 1, 2, 3, 7])
+        cover, _ = lines_walk_reference(ei, ej, ek, di, dk, rng.randrange(0, 64), es, ti, tj, run)
+        assert (cover == 1).all(), (es, ei, ej, ek, gap, di, run)
