@@ -79,7 +79,7 @@ class ExtMove(C.Structure):
 class ExtTransposePlan(C.Structure):
     _fields_ = [("noop", C.c_int32), ("exchange", C.c_int32), ("comm_axis", C.c_int32), ("nranks", C.c_int32),
                 ("comm_rank", C.c_int32), ("send_buf", C.c_int32), ("recv_buf", C.c_int32), ("n_pack", C.c_int32),
-                ("n_unpack", C.c_int32), ("reserved", C.c_int32), ("send_base", C.c_int64), ("recv_base", C.c_int64),
+                ("n_unpack", C.c_int32), ("rotate", C.c_int32), ("send_base", C.c_int64), ("recv_base", C.c_int64),
                 ("send_cnt", C.c_int64 * EXT_MAX_MEMBERS), ("send_off", C.c_int64 * EXT_MAX_MEMBERS),
                 ("recv_cnt", C.c_int64 * EXT_MAX_MEMBERS), ("recv_off", C.c_int64 * EXT_MAX_MEMBERS),
                 ("remote_recv_off", C.c_int64 * EXT_MAX_MEMBERS),
@@ -114,7 +114,7 @@ class ExtCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("graphs_captured", "graph_launches", "local", "rccl", "mpi", "peer_barrier",
                                           "peer_fused", "peer_pipelined", "direct_puts", "workspace_pool_hits",
                                           "stale_ipc_mappings", "workspace_pool_bytes", "retired_imports", "compute_queues_on_device",
-                                          "hardware_queue_slots", "relayed")]
+                                          "hardware_queue_slots", "relayed", "rotations")]
 
 
 class ExtLinkInfo(C.Structure):
@@ -505,11 +505,14 @@ def cudecompExtMove3D(src, dst, es, extent, ss, ds, force_generic=False, stream=
     return cls.value
 
 
-def cudecompExtDescribeMove(src_address, dst_address, es, extent, ss, ds, flags=0):
-    """How the kernel layer would run a move (no launch, no GPU): dict of class, variant, tile, tile counts, walk, access mode."""
+def cudecompExtDescribeMove(src_address, dst_address, es, extent, ss, ds, flags=0, row_pitch=0):
+    """How the kernel layer would run a move (no launch, no GPU): dict of class, variant, tile, tile counts, walk, access mode.
+    row_pitch: the planner's word for the move (ExtMove.row_pitch), see cudecomp_ext.h."""
     a = lambda v: (C.c_int64 * 3)(*[int(x) for x in v])
     out = (C.c_int64 * 10)()
-    _check(lib().cudecompExtDescribeMove(int(src_address), int(dst_address), es, a(extent), a(ss), a(ds), int(flags), out),
+    assert 0 <= row_pitch < (1 << 19)
+    _check(lib().cudecompExtDescribeMove(int(src_address), int(dst_address), es, a(extent), a(ss), a(ds),
+                                         int(flags) | (int(row_pitch) << 12), out),
            "cudecompExtDescribeMove")
     keys = ("cls", "variant", "tile_i", "tile_j", "tiles_i", "tiles_j", "batch", "run", "walk", "access")
     return dict(zip(keys, [int(x) for x in out]))

@@ -420,6 +420,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->self_exchange = envIsOne("CUDECOMP_TEST_SELF_EXCHANGE");
     if (const char* v = std::getenv("CUDECOMP_RCCL_NATIVE_ALLTOALL")) h->rccl_native_alltoall = std::strtol(v, nullptr, 10) != 0;
     h->direct_put = !envIsOne("CUDECOMP_DISABLE_DIRECT_PUT");
+    h->inplace_rotation = !envIsOne("CUDECOMP_DISABLE_INPLACE_ROTATION");
     h->two_hop_relay = envIsOne("CUDECOMP_TWO_HOP_RELAY");
     if (const char* v = std::getenv("CUDECOMP_FUSE_SMALL_EXCHANGES_KIB")) h->fuse_small_bytes = std::strtoll(v, nullptr, 10) << 10;
     h->debug_verify_exchange = envIsOne("CUDECOMP_DEBUG_VERIFY_EXCHANGE");
@@ -474,6 +475,8 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     tuningSwitch("CUDECOMP_LINES_MODE", &h->tuning.lines_mode);
     tuningSwitch("CUDECOMP_LINES_UNIT", &h->tuning.lines_unit);
     tuningSwitch("CUDECOMP_LINES_RUN_KIB", &h->tuning.lines_run_kib);
+    tuningSwitch("CUDECOMP_LINES_WALK", &h->tuning.lines_walk);
+    tuningSwitch("CUDECOMP_LINES_GROUP", &h->tuning.lines_group);
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))
       if (std::strtol(v, nullptr, 10) == 1) h->tuning.force_class = MOVE_GENERIC;
 

@@ -55,6 +55,7 @@ void exportTransposePlan(const TransposePlan& p, const std::vector<int>& global_
     out->recv_base = p.recv_base;
     out->n_pack = (int32_t)p.pack.size();
     out->n_unpack = (int32_t)p.unpack.size();
+    out->rotate = p.rotate;
     for (int i = 0; i < p.nranks; ++i) {
       out->member_global_rank[i] = global_ranks[i];
       if (p.exchange) {
@@ -379,6 +380,7 @@ cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDes
     out->compute_queues_on_device = handle->census_compute_queues;
     out->hardware_queue_slots = handle->census_queue_slots;
     out->relayed = gd->relayed;
+    out->rotations = gd->rotations;
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {
@@ -531,9 +533,11 @@ cudecompResult_t cudecompExtDescribeMove(uint64_t src_address, uint64_t dst_addr
       m.ds[i] = ds[i];
     }
     if (flags & 256) m.dst_row_pitch = wholeRowsPitchOf(m);
+    if (flags >> 12) m.dst_row_pitch = flags >> 12;  // the planner's own word (cudecompExtMove_t::row_pitch)
     KernelTuning t;
     if (flags & 2) t.force_streaming = true;
     if (flags & 4) t.window_mode = 1;
+    if (flags & 8) t.dense_rows = 0;  // as CUDECOMP_PRESERVE_OUTPUT_HALOS=1
     if (flags & 64) t.walk_order = 0;
     if (flags & 128) t.walk_order = 1;
     long long o[10];

@@ -86,6 +86,7 @@ struct cudecompHandle {
   bool rccl_native_alltoall = true;   // CUDECOMP_RCCL_NATIVE_ALLTOALL=0: grouped send/recv even where ncclAllToAll applies
   bool debug_verify_exchange = false;  // CUDECOMP_DEBUG_VERIFY_EXCHANGE=1: checksum what one-sided exchanges delivered (host-synchronous)
   bool direct_put = true;             // CUDECOMP_DISABLE_DIRECT_PUT=1: NVSHMEM_SM always lands in the receive area + unpack
+  bool inplace_rotation = true;       // CUDECOMP_DISABLE_INPLACE_ROTATION=1: single-rank in-place transposes always stage through the workspace
   long long pipeline_min_stage_bytes = 8ll << 20;  // CUDECOMP_PIPELINE_MIN_STAGE_MIB: no stage smaller than this
   int pipeline_stages = 4;            // CUDECOMP_PIPELINE_STAGES: stages of the one-sided pipelined exchange (1..15)
   double peer_timeout_s = 120.0;      // CUDECOMP_PEER_TIMEOUT: how long a rank waits for a peer (host rendezvous, device flags)
@@ -145,6 +146,7 @@ struct cudecompGridDesc {
   hipStream_t graph_stream = nullptr;
   int64_t graph_launches = 0;
   int64_t direct_puts = 0;  // NVSHMEM_SM transposes that wrote straight into the peers' output pencils
+  int64_t rotations = 0;    // single-rank in-place transposes executed as ONE in-place rotation kernel (kernels_rotate.hip)
   std::array<int64_t, 6> path_count{};  // transposes executed per path (cudecomp::ExecPath), for cudecompExtGetCounters
   bool graphs_failed = false;  // the runtime refused a capture: stay on plain launches
 

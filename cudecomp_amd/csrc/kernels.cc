@@ -273,9 +273,15 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
         // 16-byte lanes need whole vectors along i only: the windows run over linear positions, whatever the row length
         c.variant = (es < 16 && c.dm.e[0] % (16 / es) == 0) ? 16 / es : 1;
         c.t1 = (unsigned int)((span + ub / es - 1 + tj - 1) / tj);  // windows along the linear positions (+ one unit of phase slack)
-        const long long run = std::max<long long>(1, ((long long)(tuning ? tuning->lines_run_kib : 256) << 10) / ((long long)tj * es));
+        // tile walk (kernels_lines.hip): groups of 16 tile rows, inside a group one window after the other for all its rows
+        const long long run_kib = tuning ? tuning->lines_run_kib : 0, group = tuning ? tuning->lines_group : 16;
+        const long long run = run_kib > 0 ? std::max<long long>(1, (run_kib << 10) / ((long long)tj * es)) : 1;
         c.p0 = (long long)c.t1 >= 2 * run ? (int)run : 0;
         c.p1 = 1 | 2 | 8;  // XCD-contiguous, along the destination first, "lines"
+        if (group > 0 && group < (long long)c.t0) c.p1 |= (int)(group << 8);
+#ifdef CUDECOMP_TUNING_VARIANTS
+        if (tuning && tuning->lines_walk == 2) c.p1 |= 32;
+#endif
         c.blocks = (unsigned long long)c.t0 * c.t1;
       }
     }

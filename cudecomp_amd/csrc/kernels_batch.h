@@ -45,7 +45,7 @@ struct Batch {
 // ---- launchers, one per code object (host side; csrc/kernels.cc decides what runs) -------------------------------------------
 // stream_access: 0 default caching, 1 non-temporal loads, 2 non-temporal loads + stores, 3 non-temporal loads + remote
 // (system-scope write-through) stores, 4 cached loads + non-temporal stores (see storePolicyOf)
-// rows: mode 0 plain, 1 shifted (lanes on the destination's 64-byte grid), 2 dense (whole lines across row ends, Move3D::dst_rows_whole)
+// rows: mode 0 plain, 1 shifted (lanes on the destination's 64-byte grid), 2 dense (whole lines across row ends, Move3D::dst_row_pitch)
 void launchRowsBatch(int mode, int vector_bytes, int stream_access, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
 int rowsDenseBytesPerBlock();  // bytes of a plane's span one workgroup of the dense row copy covers
 void launchGenericBatch(int es, bool remote, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
@@ -58,5 +58,8 @@ void launchWindowBatch(int es, int variant, bool wide, int stream_access, const 
 // kernels_lines.hip: windows over the destination's linear positions across row ends (unit_bytes: 128; 64 in tuning builds)
 void launchLinesBatch(int es, int variant, int stream_access, int unit_bytes, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
 int linesUnitBytes(int unit_choice);  // the unit the build really has for a wish
+// kernels_rotate.hip: in-place rotation of a cubic n^3 array (direction +1: new[p0,p1,p2] = old[p2,p0,p1]; -1: the inverse)
+bool rotateSupported(int es, long long n);
+void launchRotate(void* buffer, long long n, int es, int direction, hipStream_t stream);
 
 }  // namespace cudecomp

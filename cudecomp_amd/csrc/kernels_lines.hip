@@ -30,7 +30,8 @@ namespace {
 // destination and written back unchanged.  Nothing is touched below a slab's first interior cell or above its last one (masked
 // pieces there).  LDS row r of a tile holds linear position lb0 + r for the TI slabs of the tile: a source row (TI elements
 // along i) when it is an interior cell, TI gathered destination cells when it is a gap cell.
-// t0 = tiles along i, t1 = windows along l; p0 = run length of the tile walk (windows), p1 bit 1 = XCD-contiguous walk.
+// t0 = tiles along i, t1 = windows along l; p0 = run length of the tile walk (windows), p1 bit 1 = XCD-contiguous walk,
+// p1 >> 8 = tile rows per group.
 // ---------------------------------------------------------------------------------------------
 template <int ES, int VW, int TI, int TJ, int STREAM, int UB>
 __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b) {
@@ -59,21 +60,28 @@ __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b
     const unsigned int per = nb >> 3;
     if (lb < (per << 3)) lt = (lb & 7u) * per + (lb >> 3);
   }
-  // walk: `run` windows along l, then the next tile row i, ..., then the next run (the last run may be shorter): the
-  // workgroups in flight on an XCD write a few long contiguous stretches of a few slabs
+  // Walk, outermost to innermost: groups of G tile rows (p1 >> 8; 0 = all of them) -- runs of R windows along l (p0; 0 = the
+  // whole range) -- the tile rows of the group -- the windows of the run.  The default (kernels.cc) is G = 16, R = 1: for one
+  // window after the other, the 16 x TI slabs of the group each get their next TJ elements -- the source is then read in
+  // whole rows, plane by plane, and every slab's write stream advances steadily (measured: profiles/r06_tuning.md).
   unsigned int bi, bl;
   {
+    const unsigned int G = (unsigned int)(b.p1[mi] >> 8) ? (unsigned int)(b.p1[mi] >> 8) : ti_n;
+    const unsigned int per_group = G * tl_n;
+    const unsigned int g = lt / per_group, x = lt - g * per_group;
+    const unsigned int gsize = (g + 1) * G <= ti_n ? G : ti_n - g * G;  // (the last group may have fewer rows)
     const unsigned int run = b.p0[mi] > 0 ? (unsigned int)b.p0[mi] : tl_n;
-    const unsigned int full_runs = tl_n / run, full = full_runs * run * ti_n;
-    if (lt < full) {
-      const unsigned int lo = lt % run, rest = lt / run;
-      bi = rest % ti_n;
-      bl = (rest / ti_n) * run + lo;
+    const unsigned int full_runs = tl_n / run, full = full_runs * run * gsize;
+    if (x < full) {
+      const unsigned int lo = x % run, rest = x / run;
+      bi = rest % gsize;
+      bl = (rest / gsize) * run + lo;
     } else {
-      const unsigned int tail = tl_n - full_runs * run, x = lt - full;
-      bl = full_runs * run + x % tail;
-      bi = x / tail;
+      const unsigned int tail = tl_n - full_runs * run, y = x - full;
+      bl = full_runs * run + y % tail;
+      bi = y / tail;
     }
+    bi += g * G;
   }
   const int ei = (int)m.e[0], ej = (int)m.e[1];
   const int dk = (int)m.ds[2];
@@ -98,7 +106,11 @@ __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b
     for (int p = 0; p < NP; ++p) {
       const int jj = lj + p * RPP;
       if (jj < ROWS && (interior || (i0 + li < ei && l >= 0 && l < L))) {
+#ifdef CUDECOMP_TUNING_VARIANTS
+        if (j < ej || (b.p1[mi] & 32)) {  // (bit 32, measurements only: no gap gather -- the gap cells come back WRONG)
+#else
         if (j < ej) {
+#endif
           regs[p] = loadVec<loadsStream<STREAM>(), ES * VW>(src + (long long)k * sk + (long long)j * sj + i0 + li);
         } else {  // a gap cell of every slab of the tile: what the destination holds there goes back unchanged
 #pragma unroll

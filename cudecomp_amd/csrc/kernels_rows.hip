@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void rows_shifted_kernel(const Batch b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// rows_dense_kernel: row copy onto a halo-carrying pencil whose rows the move covers WHOLE (Move3D::dst_rows_whole).
+// rows_dense_kernel: row copy onto a halo-carrying pencil whose rows the move covers WHOLE (Move3D::dst_row_pitch).
 // What costs on such destinations is not the misalignment but every 128-byte line that is only partly written -- the two
 // lines at the ends of each row, about four line times each (profiles/r05_tuning.md section 3: 8 GiB onto rows of 8192 B at a
 // pitch of 8208 B 3.25 ms against 2.85 ms aligned).  Here the lanes walk the destination's LINEAR address space on the 64-byte

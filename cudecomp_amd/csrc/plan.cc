@@ -107,6 +107,12 @@ TransposePlan buildTransposePlan(const GridShape& g, int rank, TransposeOp op, c
       p.pack.push_back(blockMove(BUF_IN, ah.interiorOffset(), ast, BUF_WORK, 0, wst, Sa, 0));
       p.unpack.push_back(blockMove(BUF_WORK, 0, wst, BUF_OUT, bh.interiorOffset(), bst, Sb, 0));
       p.unpack.back().dst_row_pitch = Sb[b.order[0]] > 1 ? bst[b.order[1]] : 0;
+      // cubic and halo-free: memory position i of the input holds axis a.order[i]; the output wants b.order[i] there
+      if (!in_hp && !out_hp && Sa[0] == Sa[1] && Sa[1] == Sa[2] && Sa[0] > 1) {
+        if (a.order[0] == b.order[2] && a.order[1] == b.order[0] && a.order[2] == b.order[1]) p.rotate = 1;    // new[p] = old[p2,p0,p1]
+        if (a.order[0] == b.order[1] && a.order[1] == b.order[2] && a.order[2] == b.order[0]) p.rotate = -1;   // new[p] = old[p1,p2,p0]
+        if (p.rotate) p.rotate_n = Sa[0];
+      }
     }
     p.schedule_dst = {0};
     p.schedule_src = {0};

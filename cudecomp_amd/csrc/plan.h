@@ -31,8 +31,12 @@ struct Move3D {
   // along the fastest memory axis) and this is the pencil's row pitch in elements.  The cells between the end of one row and
   // the start of the row one pitch further are then halo / padding cells of that pencil, written by nobody during the
   // operation, and the kernel layer may write whole cache lines across the row ends, putting back into those cells what it
-  // read from them (rows_dense_kernel, kernels_rows.hip).  Only ever set for local destinations (never for puts into a
-  // peer's pencil).
+  // read from them (rows_dense_kernel, kernels_rows.hip; transpose_lines_kernel, kernels_lines.hip).  Only ever set for
+  // local destinations (never for puts into a peer's pencil).  THE RULE this rests on: during a transpose nobody writes the
+  // halo / padding cells of its output pencil -- no move of the plan (checked over random decompositions, tests/test_plan_sim.py),
+  // no one-sided write of a peer (direct puts address interior cells, halo plans never target a peer's pencil: they exchange
+  // through workspaces or whole contiguous faces, buildHaloPlan), and no kernel of the caller on another stream (the
+  // documented contract; CUDECOMP_PRESERVE_OUTPUT_HALOS=1 for callers who cannot promise that).
   i64 dst_row_pitch = 0;
 
   i64 elements() const { return extent[0] * extent[1] * extent[2]; }
@@ -80,6 +84,13 @@ struct TransposePlan {
   // (dst_off / ds are relative to the peer's output buffer) -- one HBM pass per element, no receive area, no unpack.
   // Same order as `pack` (peers in schedule order, self last).  Empty when the plan has no such form (in place).
   std::vector<Move3D> direct;
+
+  // Single-rank, in place, cubic, no halos / padding, and the two memory orders a rotation of each other: the whole
+  // operation is the in-place rotation new[p0,p1,p2] = old[p2,p0,p1] (+1) or its inverse (-1) of an n^3 array -- one read
+  // and one write per element where pack + unpack through the workspace (which stay in the plan: the kernel layer says
+  // whether it has the rotation for the element size, kernels_rotate.hip) need two of each.  0: no such form.
+  int rotate = 0;
+  i64 rotate_n = 0;
 
   i64 pencil_elements_a = 0;  // interior elements moved (for bandwidth accounting)
 };

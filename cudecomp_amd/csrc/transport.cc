@@ -119,7 +119,7 @@ class PeerContext {
 
   ~PeerContext() {
     if (board_registered_) (void)hipHostUnregister(board_);
-    if (board_) ::munmap(board_, board_bytes_);
+    if (board_) unmapBoard(board_, board_bytes_);
     for (auto& kv : regions_) closePeers(kv.second);
     for (auto& pk : pool_) (void)hipFree(pk.base);  // parked workspaces: released with the library
     for (auto& kv : imports_)
@@ -717,6 +717,51 @@ class PeerContext {
     return *reinterpret_cast<Mail*>(board_ + mail_off_ + (((size_t)slot * h_->nranks + rank) * 2 + parity) * kMailBytes);
   }
 
+  // Where a board is mapped.  The board is registered with HIP and polled by kernels; a process that finalizes a handle and
+  // creates another (a job server, a long-lived test worker) would normally get the NEW board at the address the old one
+  // had -- and on this platform a compute die can keep serving the old translation of a recycled address (the family of
+  // profiles/r05_stale_xcd_view.md; round 6: wait kernels of a re-created handle read the flags of its predecessor's board
+  // and let unpacks run ahead of their data, profiles/r06_board_address_reuse.md).  So boards are placed in a reserved
+  // address arena, each at a fresh address, and a retired board's range stays reserved: no board address is ever used twice
+  // by a process.  CUDECOMP_BOARD_FRESH_ADDRESS=0 restores plain mmap (debugging).
+  static constexpr size_t kArenaBytes = (size_t)4 << 30, kArenaAlign = (size_t)2 << 20;
+  static char*& arenaBase() {
+    static char* base = nullptr;
+    return base;
+  }
+  static size_t& arenaUsed() {
+    static size_t used = 0;
+    return used;
+  }
+  static bool freshAddresses() {
+    const char* v = std::getenv("CUDECOMP_BOARD_FRESH_ADDRESS");
+    return !v || std::strtol(v, nullptr, 10) != 0;
+  }
+  void* mapBoard(int fd, size_t bytes) {
+    board_in_arena_ = false;
+    if (freshAddresses()) {
+      if (!arenaBase()) {
+        void* a = ::mmap(nullptr, kArenaBytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (a != MAP_FAILED) arenaBase() = static_cast<char*>(a);
+      }
+      const size_t need = (bytes + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
+      if (arenaBase() && arenaUsed() + need <= kArenaBytes) {
+        void* p = ::mmap(arenaBase() + arenaUsed(), bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, 0);
+        if (p != MAP_FAILED) {
+          arenaUsed() += need;
+          board_in_arena_ = true;
+          return p;
+        }
+      }
+    }
+    return ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  }
+  void unmapBoard(void* p, size_t bytes) {
+    // inside the arena the range goes back to "reserved, inaccessible": the shared pages are dropped, the address is not reused
+    if (board_in_arena_) (void)::mmap(p, bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0);
+    else ::munmap(p, bytes);
+  }
+
   void openBoard() {
     // every host gets its own segment; its name is agreed through the bootstrap, the creator unlinks it as
     // soon as all local ranks have mapped it, so nothing is left behind even if a rank crashes later
@@ -748,13 +793,13 @@ class PeerContext {
     }
     h_->boot->barrier();
     if (h_->local_rank != 0) fd = ::shm_open(shm_name, O_RDWR, 0600);
-    void* p = (fd >= 0) ? ::mmap(nullptr, board_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+    void* p = (fd >= 0) ? mapBoard(fd, board_bytes_) : MAP_FAILED;
     if (fd >= 0) ::close(fd);
     const bool ok = (p != MAP_FAILED);
     const bool all_ok = !h_->boot->allreduceOr(!ok);  // also: everybody has mapped it
     if (h_->local_rank == 0) ::shm_unlink(shm_name);
     if (ok && all_ok) board_ = static_cast<char*>(p);
-    else if (ok) ::munmap(p, board_bytes_);  // bootstrap barriers, no one-sided transport
+    else if (ok) unmapBoard(p, board_bytes_);  // bootstrap barriers, no one-sided transport
   }
 
   cudecompHandle_t h_;
@@ -781,6 +826,7 @@ class PeerContext {
   bool peer_access_done_ = false;
   bool debug_ = false;
   bool board_registered_ = false;
+  bool board_in_arena_ = false;
   char* board_ = nullptr;
   char* dboard_ = nullptr;
   size_t board_bytes_ = 0, flags_off_ = 0, mail_off_ = 0, status_off_ = 0, flag_row_bytes_ = 0;
@@ -968,6 +1014,20 @@ void peerMeasureLink(cudecompHandle_t h) {
   h->boot->allgather(bus, all.data(), 64);
   const int next = (h->rank + 1) % h->nranks;
   h->link_crosses_devices = std::strncmp(all.data() + (size_t)64 * next, bus, 64) != 0;
+  // Ranks that SHARE a GPU are a test configuration, and one with a known platform hazard (DESIGN.md section 9,
+  // profiles/r05_stale_xcd_view.md): a buffer that a process frees and re-allocates while its peers hold IPC mappings of
+  // the pooled workspaces is sometimes served stale by ONE XCD, before any library call.  Production -- one process per GPU,
+  // memory never recycled between processes -- is not exposed; a program that runs this way hears about it once.
+  static bool warned_shared = false;
+  if (!h->link_crosses_devices && h->rank == 0 && !warned_shared && !std::getenv("CUDECOMP_WORKSPACE_POOL_MIB")) {
+    const char* quiet = std::getenv("CUDECOMP_SHARED_GPU_WARNING");
+    if (!quiet || std::strtol(quiet, nullptr, 10) != 0)
+      fprintf(stderr, "CUDECOMP:WARN: the ranks of this job share a GPU (a test configuration).  Known platform behaviour: data buffers "
+                      "that are freed and re-allocated between calls while peers hold IPC mappings of pooled workspaces can be read stale "
+                      "by one XCD; keep data buffers alive across calls or set CUDECOMP_WORKSPACE_POOL_MIB=0 "
+                      "(CUDECOMP_SHARED_GPU_WARNING=0 silences this line).\n");
+    warned_shared = true;
+  }
   const size_t bytes = (size_t)64 << 20;
   char* buf = nullptr;
   bool ok = true;
@@ -1429,7 +1489,14 @@ bool peerRelayEnsureRegion(cudecompHandle_t h, const RelayPlan& rp, int es) {
   // the same number on every rank (it is derived from the whole decomposition), so this is collective by construction
   const size_t need = (size_t)rp.relayElements() * es;
   if (h->relay_buf && h->relay_bytes >= need) return true;
-  if (h->relay_buf) workspaceFreeRaw(h, h->relay_buf);
+  if (h->relay_buf) {
+    // Regrowing: my previous relayed call (possibly on another stream) and my peers' previous scatters into the region must be
+    // over before it goes away.  Mine: the event every relayed call ends with (never recorded if that call threw before
+    // its end -- a deliberate no-op then); the peers': a barrier after everybody has waited for its own.
+    if (h->relay_last_call) CD_CHECK_HIP(hipEventSynchronize(h->relay_last_call));
+    h->boot->barrier();
+    workspaceFreeRaw(h, h->relay_buf);
+  }
   h->relay_buf = nullptr;
   h->relay_bytes = 0;
   void* p = workspaceAllocRaw(h, need, true);

@@ -5,6 +5,7 @@
 #include "errors.h"
 #include "internal.h"
 #include "transport.h"
+#include "kernels_batch.h"
 
 namespace cudecomp {
 
@@ -239,6 +240,15 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
   void* const work = bufs[2];
   if (!plan.exchange) {
     gd->path_count[PATH_LOCAL]++;
+    if (plan.rotate && input == output && h->inplace_rotation && rotateSupported(es, plan.rotate_n)) {
+      // in place on a cubic 1 x 1 grid: one rotation kernel, one read and one write per element (kernels_rotate.hip)
+      launchRotate(input, plan.rotate_n, es, plan.rotate, stream);
+      gd->rotations++;
+      perfMark(pev, 1, stream);
+      perfMark(pev, 2, stream);
+      perfMark(pev, 3, stream);
+      return;
+    }
     launchMoves(plan.pack.data(), (int)plan.pack.size(), bufs, es, stream, &h->tuning);
     perfMark(pev, 1, stream);
     perfMark(pev, 2, stream);

@@ -32,7 +32,8 @@ typedef struct {
   int32_t exchange; /* an all-to-all happens between pack and unpack */
   int32_t comm_axis /* 0 column, 1 row */, nranks, comm_rank;
   int32_t send_buf, recv_buf;
-  int32_t n_pack, n_unpack, reserved;
+  int32_t n_pack, n_unpack;
+  int32_t rotate;  /* single-rank in place on a cubic halo-free grid: +1 / -1 = the operation is the in-place rotation new[p0,p1,p2] = old[p2,p0,p1] / its inverse (pack + unpack stay as the staged alternative); 0 = no such form */
   int64_t send_base, recv_base; /* elements */
   int64_t send_cnt[CUDECOMP_EXT_MAX_MEMBERS], send_off[CUDECOMP_EXT_MAX_MEMBERS];
   int64_t recv_cnt[CUDECOMP_EXT_MAX_MEMBERS], recv_off[CUDECOMP_EXT_MAX_MEMBERS];
@@ -175,6 +176,7 @@ typedef struct {
   int64_t compute_queues_on_device, hardware_queue_slots;
   /* transposes of this descriptor whose exchange went through the two-hop relay (CUDECOMP_TWO_HOP_RELAY=1) */
   int64_t relayed;
+  int64_t rotations;   /* single-rank in-place transposes run as one in-place rotation kernel */
 } cudecompExtCounters_t;
 cudecompResult_t cudecompExtGetCounters(cudecompHandle_t handle, cudecompGridDesc_t grid_desc,
                                         cudecompExtCounters_t* counters);
@@ -227,8 +229,10 @@ cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const
  * GPU): out[10] = {class (0 rows, 1 LDS transpose, 2 generic), kernel variant, tile_i, tile_j, tiles_i, tiles_j, batch extent,
  * run length of the tile walk, walk bits (1 XCD-contiguous, 2 j first, 4 runs over batch planes), access mode}.  flags: 2 =
  * streaming access regardless of the size, 4 = window / shifted variants regardless of the size, 64 / 128 = force the i-first /
- * j-first walk, 256 = whole destination rows (as cudecompExtMove3D).  Row copies report their kernel in the tile_i slot
- * (0 plain, 1 shifted, 2 dense).  Harness-only (tests/test_kernel_plan.py). */
+ * j-first walk, 256 = whole destination rows (as cudecompExtMove3D), 8 = never rewrite the cells between rows (what
+ * CUDECOMP_PRESERVE_OUTPUT_HALOS=1 does), flags >> 12 = the destination pencil's row pitch as the planner reports it
+ * (cudecompExtMove_t::row_pitch; 0 = none).  Walk bit 8 = transpose_lines_kernel.  Row copies report their kernel in the
+ * tile_i slot (0 plain, 1 shifted, 2 dense).  Harness-only (tests/test_kernel_plan.py). */
 cudecompResult_t cudecompExtDescribeMove(uint64_t src_address, uint64_t dst_address, int32_t es, const int64_t extent[3],
                                         const int64_t ss[3], const int64_t ds[3], int32_t flags, int64_t out[10]);
 

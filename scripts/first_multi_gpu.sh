@@ -93,8 +93,9 @@ fi
 step "4 bench.py at 2 / 4 / 8 ranks"
 for n in 2 4 8; do
   [ $n -le $MAXR ] || continue
-  ( time timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2953$n \
-      bench.py --gpus $n --steps $STEPS --warmup $WARM --size $SIZE ) > $OUT/04_bench_n$n.log 2>&1
+  # (as a plain command: bench.py starts its own ranks under torch.distributed.run when no launcher is around it -- the
+  # way the driver called `--gpus 1`; the driver's own multi-GPU line with torch.distributed.run in front works alike)
+  ( time timeout 1500 python bench.py --gpus $n --steps $STEPS --warmup $WARM --size $SIZE ) > $OUT/04_bench_n$n.log 2>&1
   grep -E '^\{' $OUT/04_bench_n$n.log | tail -1 > $OUT/04_bench_n$n.json
   echo "   n=$n: $(python -c "import json,sys; r=json.load(open('$OUT/04_bench_n$n.json')); print(r['ms_per_step'], 'ms per cycle,', r['config']['transport'], r['config']['pdims'])" 2>&1 | tail -1)" | tee -a $OUT/00_plan.txt
 done

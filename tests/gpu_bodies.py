@@ -441,7 +441,10 @@ def graph_cycle(rank, nranks, args):
         cycle(stream.cuda_stream)  # warm-up: first-use allocations and mappings happen outside the capture
         stream.synchronize()
         if not torch.equal(a[:x0.numel()], x0) or not torch.equal(z[:z0.numel()], z0):
-            failures.append("rank %d: eager warm-up cycle wrong" % rank)
+            bad_x, bad_z = (a[:x0.numel()] != x0).nonzero().flatten(), (z[:z0.numel()] != z0).nonzero().flatten()
+            failures.append("rank %d: eager warm-up cycle wrong: X pencil %d cells (first %s), Z pencil %d cells (first %s, holds %s)"
+                            % (rank, bad_x.numel(), bad_x[:3].tolist(), bad_z.numel(), bad_z[:3].tolist(),
+                               z[bad_z[:3]].tolist() if bad_z.numel() else []))
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
         cycle(torch.cuda.current_stream().cuda_stream)
@@ -886,3 +889,8 @@ def small_cycle_latency(rank, nranks, args):
     cd.cudecompFree(h, gd, work)
     cd.cudecompGridDescDestroy(h, gd)
     return {"us_per_transpose": dt / (4 * n) * 1e6}
+
+
+def graph_cycle_failures(rank, nranks, args):
+    """graph_cycle for the `many` runner (a list of failure strings)."""
+    return graph_cycle(rank, nranks, args)["failures"]

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 _port_counter = [0]
+_port_lock = __import__("threading").Lock()
 
 
 def free_port():
@@ -25,8 +26,10 @@ def free_port():
     ephemeral range (so no other process is handed it for an outgoing connection in the meantime), walking a
     per-process sequence."""
     for _ in range(2000):
-        _port_counter[0] += 1
-        port = 10000 + (os.getpid() * 131 + _port_counter[0] * 17) % 20000
+        with _port_lock:
+            _port_counter[0] += 1
+            count = _port_counter[0]
+        port = 10000 + (os.getpid() * 131 + count * 17) % 20000
         s = socket.socket()
         try:
             s.bind(("127.0.0.1", port))
@@ -494,3 +497,38 @@ def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
             pass
         raise AssertionError("\n".join(failures))
     return logs
+
+
+def run_binary_groups(jobs, max_ranks=8):
+    """Several INDEPENDENT native launches side by side -- jobs = [(nranks, argv, timeout, extra_env), ...] -- as long as
+    together they stay within `max_ranks` processes on the GPU (the device serves eight processes without time-slicing them,
+    DESIGN.md section 9).  The test programs spend most of their time on the host (filling and comparing pencils, the control
+    plane of a descriptor per case), so two four-rank groups take about as long as one.  Returns the per-job logs in order;
+    raises the first failure after all jobs have ended."""
+    from concurrent.futures import ThreadPoolExecutor
+    pool_stop()
+    results, errors = [None] * len(jobs), []
+    batch, used = [], 0
+
+    def flush():
+        if not batch:
+            return
+        with ThreadPoolExecutor(max_workers=len(batch)) as ex:
+            futs = [(i, ex.submit(run_binary_ranks, n, argv, timeout, env)) for i, (n, argv, timeout, env) in batch]
+            for i, f in futs:
+                try:
+                    results[i] = f.result()
+                except AssertionError as e:
+                    errors.append(e)
+        batch.clear()
+
+    for i, job in enumerate(jobs):
+        if used + job[0] > max_ranks:
+            flush()
+            used = 0
+        batch.append((i, job))
+        used += job[0]
+    flush()
+    if errors:
+        raise errors[0]
+    return results

@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_MPI_P2P, cd.TRANSPOSE_COMM_NVSHMEM, cd.TRANSPOSE_COMM_NVSHMEM_SM],
                          ids=["mpi_p2p_host_rendezvous", "nvshmem_device_wait", "nvshmem_sm"])
 def test_absent_peer_is_reported_not_waited_for_forever(backend):
-    args = {"gdims": (32, 24, 40), "pdims": (2, 1), "kind": 1, "transpose_backend": backend, "absent_for": 6.0}
-    res = run_ranks(2, "tests.gpu_bodies", "absent_peer", args, timeout=120, extra_env={"CUDECOMP_PEER_TIMEOUT": "2"})
+    args = {"gdims": (32, 24, 40), "pdims": (2, 1), "kind": 1, "transpose_backend": backend, "absent_for": 5.0}
+    res = run_ranks(2, "tests.gpu_bodies", "absent_peer", args, timeout=120, extra_env={"CUDECOMP_PEER_TIMEOUT": "1.5"})
     r0 = [r for r in res if r["rank"] == 0][0]
     assert r0["error_code"] == cd.RESULT_NVSHMEM_ERROR, r0
-    assert 1.5 < r0["seconds"] < 5.5, r0  # PEER_TIMEOUT = 2 s; the absent rank stays away for 6 s
+    assert 1.0 < r0["seconds"] < 4.5, r0  # PEER_TIMEOUT = 1.5 s; the absent rank stays away for 5 s

@@ -77,22 +77,32 @@ def _dtypes(config):
     return ALL_DTYPES if config in ("transpose_test_cc", "halo_test_cc") else ["R32"]
 
 
+def _run_mpi_jobs(jobs):
+    """jobs = [(binary, lines)]: two mpirun launches of four ranks at a time (eight processes on the GPU, the programs are
+    host-bound); returns the outputs in order."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import mp
+    mp.pool_stop()
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        return list(ex.map(lambda j: _run_mpi(*j), jobs))
+
+
 def test_mpi_flavour_transposes_over_the_reference_matrix():
     """MPI_P2P (1), MPI_P2P_PL (2), MPI_A2A (3): >= 500 cases, every one through csrc/bootstrap_mpi.cc:mpiAlltoall."""
     _need()
     configs = load_cases()
-    total = through_mpi = 0
+    jobs, labels = [], []
     for config, step in sorted(TRANSPOSE_STEP.items()):
         lines = [l for l in configs[config] if _backend(l) in (1, 2, 3)]
         for k, dtype in enumerate(_dtypes(config)):
-            pick = lines[k % step::step]
-            text = _run_mpi("transpose_test_" + dtype, pick)
-            n = int(re.search(r"MPI-path transposes: (\d+)", text).group(1))
-            # every hop of every case whose communicator has more than one member exchanges through MPI; 1xN / Nx1 grids
-            # have two local hops per cycle
-            assert n > 0, "%s %s: no transpose took the MPI path" % (config, dtype)
-            total += len(pick)
-            through_mpi += n
+            jobs.append(("transpose_test_" + dtype, lines[k % step::step]))
+            labels.append((config, dtype))
+    total = through_mpi = 0
+    for (config, dtype), (binary, pick), text in zip(labels, jobs, _run_mpi_jobs(jobs)):
+        n = int(re.search(r"MPI-path transposes: (\d+)", text).group(1))
+        assert n > 0, "%s %s: no transpose took the MPI path" % (config, dtype)
+        total += len(pick)
+        through_mpi += n
     assert total >= 500, total
     assert through_mpi >= 4 * total  # 4 ranks x (at least 2 exchanging hops of 4) x ... per case, summed over ranks
 
@@ -101,14 +111,13 @@ def test_mpi_flavour_halos_over_the_reference_matrix():
     """HALO_COMM_MPI (1) and HALO_COMM_MPI_BLOCKING (2) through csrc/bootstrap_mpi.cc:mpiHaloExchange."""
     _need()
     configs = load_cases()
-    total = 0
+    jobs = []
     for config, step in sorted(HALO_STEP.items()):
         lines = [l for l in configs[config] if _backend(l) in (1, 2)]
         for k, dtype in enumerate(_dtypes(config)):
-            pick = lines[k % step::step]
-            _run_mpi("halo_test_" + dtype, pick)
-            total += len(pick)
-    assert total >= 250, total
+            jobs.append(("halo_test_" + dtype, lines[k % step::step]))
+    _run_mpi_jobs(jobs)
+    assert sum(len(j[1]) for j in jobs) >= 250
 
 
 def test_mpi_flavour_gpu_aware_path():

@@ -24,16 +24,7 @@ def _binary(name):
     return path
 
 
-def _run(binary, nranks, lines, env=None):
-    """Runs the case list through the native test program (reference protocol: every case PASSED, "Passed all tests.").
-    Every failure is a failure: nothing is repeated."""
-    with tempfile.NamedTemporaryFile("w", suffix="_cases.txt", delete=False) as f:
-        f.write("\n".join(lines) + "\n")
-        path = f.name
-    try:
-        logs = run_binary_ranks(nranks, [_binary(binary), "--testfile", path], timeout=900, extra_env=env)
-    finally:
-        os.unlink(path)
+def _check_logs(binary, lines, logs):
     out = logs[0]
     ok = out.count(" PASSED") == len(lines) and " FAILED" not in out and "Passed all tests." in out
     if not ok:  # keep every rank's output where gpurun merges it back
@@ -42,6 +33,32 @@ def _run(binary, nranks, lines, env=None):
             for r, text in enumerate(logs):
                 f.write("===== rank %d =====\n%s\n" % (r, text[-20000:]))
     assert ok, out[-3000:]
+
+
+def _run(binary, nranks, lines, env=None):
+    """Runs the case list through the native test program (reference protocol: every case PASSED, "Passed all tests.").
+    Every failure is a failure: nothing is repeated."""
+    _run_side_by_side([(binary, nranks, lines, env)])
+
+
+def _run_side_by_side(jobs, path_of=None):
+    """jobs = [(binary, nranks, lines, env)]: independent case lists, launched together while they fit on the GPU side by side
+    (tests/mp.py: run_binary_groups); every list is checked like _run's."""
+    from tests.mp import run_binary_groups
+    paths, groups = [], []
+    for binary, nranks, lines, env in jobs:
+        with tempfile.NamedTemporaryFile("w", suffix="_cases.txt", delete=False) as f:
+            f.write("\n".join(lines) + "\n")
+            paths.append(f.name)
+        exe = path_of(binary) if path_of else _binary(binary)
+        groups.append((nranks, [exe, "--testfile", paths[-1]], 900, env))
+    try:
+        all_logs = run_binary_groups(groups)
+    finally:
+        for p in paths:
+            os.unlink(p)
+    for (binary, nranks, lines, env), logs in zip(jobs, all_logs):
+        _check_logs(binary, lines, logs)
 
 
 def _transpose_lines(pdims_list, backends, full):

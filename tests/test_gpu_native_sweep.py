@@ -13,7 +13,7 @@ import os
 
 import pytest
 
-from tests.test_gpu_native import SHIM, _run
+from tests.test_gpu_native import SHIM, _run, _run_side_by_side
 
 pytestmark = pytest.mark.gpu
 PERMS = [" ".join(map(str, p)) for p in itertools.permutations((0, 1, 2))]
@@ -178,14 +178,15 @@ def _switch_sweep(env):
                      extra="--acx 1 --acy 1 --acz 1", oop=oop) for (pr, pc), b, oop in itertools.product(PDIMS, (2, 8), (True, False))]
     lines += [_tcase(pr, pc, 8, hx="2 1 1", hy="1 2 1", hz="1 1 2", extra=mo + " -m", oop=True)   # direct put onto halo-shifted rows
               for (pr, pc), mo in itertools.product(PDIMS, _mem_orders()[::7])]
-    _run("transpose_test_R64", 4, lines, dict(env))
+    jobs = [("transpose_test_R64", 4, lines, dict(env))]
     if "CUDECOMP_WINDOW_STORES" in env:
         for dtype in ("R32", "C64"):
-            _run("transpose_test_" + dtype, 4, [l for l in lines if "--hex 0 0 0" not in l], dict(env))
+            jobs.append(("transpose_test_" + dtype, 4, [l for l in lines if "--hex 0 0 0" not in l], dict(env)))
     hl = [_hcase(pr, pc, b, ax, h=(1, 2, 1), pad=(1, 0, 0)) for (pr, pc), ax, b in itertools.product(PDIMS, (0, 1, 2), (1, 3))]
     henv = dict(env)
     if os.path.exists(SHIM):
         henv["LD_PRELOAD"] = SHIM  # backend 3 (RCCL code path) with four ranks on one GPU
     else:
         hl = [l for l in hl if "--backend 3" not in l]
-    _run("halo_test_R64", 4, hl, henv)
+    jobs.insert(1, ("halo_test_R64", 4, hl, henv))
+    _run_side_by_side(jobs)  # the transposes and the halo updates of a switch side by side: two four-rank groups share the GPU

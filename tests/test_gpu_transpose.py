@@ -140,6 +140,25 @@ def test_bench_workload_every_cell(ac, inplace):
         assert r["failures"] == []
 
 
+@pytest.mark.parametrize("kind", [1, 2, 3])
+def test_in_place_rotation_of_cubic_grids(kind):
+    """Single rank, in place, cubic, axis-contiguous: every hop is ONE in-place rotation kernel (csrc/kernels_rotate.hip; the
+    reference stages such transposes through the workspace, include/internal/transpose.h:326-362).  Against the oracle after
+    every hop; cubes the tiles divide run it (counted), others and CUDECOMP_DISABLE_INPLACE_ROTATION keep the staged form."""
+    tile = 8 if kind == 3 else 16
+    for n in (tile, 2 * tile, 3 * tile, 5 * tile):
+        args = {"gdims": (n, n, n), "pdims": (1, 1), "ac": K.ALL_AC, "kind": kind, "out_of_place": [False], "expect_path": ["rotations"]}
+        assert B.transpose_chain(0, 1, args) == []
+    # a cube the tiles do not divide, a non-cubic grid, fp32: staged, same results
+    for gdims, k in (((tile + 4,) * 3, kind), ((32, 32, 48), kind), ((32, 32, 32), 0)):
+        args = {"gdims": gdims, "pdims": (1, 1), "ac": K.ALL_AC, "kind": k, "out_of_place": [False]}
+        assert B.transpose_chain(0, 1, args) == []
+    h = B._handle(0)
+    gd = cd.cudecompGridDescCreate(h, cd.make_config((tile + 4,) * 3, (1, 1), axis_contiguous=K.ALL_AC))
+    assert cd.cudecompExtGetCounters(h, gd)["rotations"] == 0
+    cd.cudecompGridDescDestroy(h, gd)
+
+
 def test_more_than_2_31_elements_per_pencil_every_cell():
     """Maximum-size edge, every cell: 2048 x 1024 x 1056 fp32 = 2.2e9 elements (> 2^31) in one pencil, each hop compared
     on the device with the closed form (low 31 bits of the global linear index, which itself exceeds 2^31)."""

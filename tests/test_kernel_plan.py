@@ -216,9 +216,9 @@ def test_lines_kernel_is_chosen_for_forward_hops_onto_halo_pencils_only():
     d = lines_shape(1024, 1024, 1022, 1)
     assert d["cls"] == 1 and d["walk"] & LINES and (d["tile_i"], d["tile_j"], d["access"]) == (64, 64, 4), d
     span = 1021 * 1026 + 1024
-    assert d["tiles_i"] == 16 and d["tiles_j"] == -(-(span + 15) // 64) and d["run"] * 64 * 8 == 256 << 10, d
+    assert d["tiles_i"] == 16 and d["tiles_j"] == -(-(span + 15) // 64) and d["run"] == 1 and d["walk"] >> 8 == 0, d  # 16 tile rows: one group
     c5 = lines_shape(2048, 2048, 256, 2)  # config 5's pencil shape on a 1 x 1 grid
-    assert c5["walk"] & LINES and c5["variant"] == 2, c5
+    assert c5["walk"] & LINES and c5["variant"] == 2 and c5["tiles_i"] == 32 and c5["walk"] >> 8 == 16 and c5["run"] == 1, c5
     for es in (4, 16):
         assert lines_shape(1024, 1024, 64, 1, es=es)["walk"] & LINES
     # without the planner's word the gap cells are not the move's: the window kernel
@@ -236,35 +236,38 @@ def test_lines_kernel_is_chosen_for_forward_hops_onto_halo_pencils_only():
     # small moves stay with the plain tile kernel unless asked (flag 4), like the window kernel
     assert not lines_shape(128, 128, 4, 1)["walk"] & LINES
     small = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (128, 128, 8), (1, 128, 128 * 128), (130 * 10, 1, 130), flags=WHOLE | 4)
-    assert small["walk"] & LINES and small["run"] == 0, small
+    assert small["walk"] & LINES and small["run"] == 1, small
     # an odd row count along i: element-wise lanes (vectors hold whole elements along i only)
     assert lines_shape(1023, 1024, 64, 1)["variant"] == 1
     assert lines_shape(1024, 1023, 64, 1)["variant"] == 2   # the row length does not matter
 
 
-def lines_walk_reference(ei, ej, ek, di, dk, dst_phase, es, ti, tj, run, ub=128):
+def lines_walk_reference(ei, ej, ek, di, dk, dst_phase, es, ti, tj, run, group=0, ub=128):
     """numpy restatement of transpose_lines_kernel's decode: which (slab i, linear position l) every workgroup stores.
-    Returns the coverage count per (i, l) over [0, L) and the number of stores that would fall outside."""
+    Returns the coverage count per (i, l) over [0, L)."""
     U = ub // es
     L = (ek - 1) * dk + ej
     ti_n, tl_n = -(-ei // ti), -(-(L + U - 1) // tj)
     cover = np.zeros((ei, L), dtype=np.int32)
-    outside = 0
     nb = ti_n * tl_n
     per = nb >> 3
     seen = set()
+    G = group if group else ti_n
     for lb in range(nb):
         lt = (lb & 7) * per + (lb >> 3) if lb < (per << 3) else lb
+        g, x = divmod(lt, G * tl_n)
+        gsize = G if (g + 1) * G <= ti_n else ti_n - g * G
         r = run if run > 0 else tl_n
         full_runs = tl_n // r
-        full = full_runs * r * ti_n
-        if lt < full:
-            lo, rest = lt % r, lt // r
-            bi, bl = rest % ti_n, (rest // ti_n) * r + lo
+        full = full_runs * r * gsize
+        if x < full:
+            lo, rest = x % r, x // r
+            bi, bl = rest % gsize, (rest // gsize) * r + lo
         else:
-            tail, x = tl_n - full_runs * r, lt - full
-            bl, bi = full_runs * r + x % tail, x // tail
-        assert (bi, bl) not in seen and bi < ti_n and bl < tl_n
+            tail, y = tl_n - full_runs * r, x - full
+            bl, bi = full_runs * r + y % tail, y // tail
+        bi += g * G
+        assert (bi, bl) not in seen and bi < ti_n and bl < tl_n, (bi, bl, ti_n, tl_n, lt)
         seen.add((bi, bl))
         lb0 = bl * tj - (U - 1)
         for i in range(bi * ti, min(ei, bi * ti + ti)):
@@ -275,7 +278,7 @@ def lines_walk_reference(ei, ej, ek, di, dk, dst_phase, es, ti, tj, run, ub=128)
             if b > a:
                 cover[i, a:b] += 1
     assert len(seen) == nb
-    return cover, outside
+    return cover
 
 
 def test_lines_walk_covers_every_cell_of_every_slab_exactly_once():
@@ -283,10 +286,80 @@ def test_lines_walk_covers_every_cell_of_every_slab_exactly_once():
     for _ in range(60):
         es = rng.choice([4, 8, 16])
         ti, tj = {4: (64, 128), 8: (64, 64), 16: (32, 32)}[es]
-        ei, ej, ek = rng.choice([32, 64, 100, 130]), rng.choice([160, 200, 257, 300]), rng.choice([2, 3, 5, 9])
+        ei, ej, ek = rng.choice([32, 64, 100, 130, 200, 330]), rng.choice([160, 200, 257, 300]), rng.choice([2, 3, 5, 9])
         gap = rng.choice([1, 2, 3, 4, 6])
         dk = ej + gap
         di = dk * (ek + rng.choice([0, 1, 2])) + rng.choice([0, 1, 5])
-        run = rng.choice([0, 1, 2, 3, 7])
-        cover, _ = lines_walk_reference(ei, ej, ek, di, dk, rng.randrange(0, 64), es, ti, tj, run)
-        assert (cover == 1).all(), (es, ei, ej, ek, gap, di, run)
+        run, group = rng.choice([0, 1, 2, 3, 7]), rng.choice([0, 0, 1, 2, 3])
+        cover = lines_walk_reference(ei, ej, ek, di, dk, rng.randrange(0, 64), es, ti, tj, run, group)
+        assert (cover == 1).all(), (es, ei, ej, ek, gap, di, run, group)
+
+
+# ---- single-rank in-place transposes of cubic grids: the in-place rotation (csrc/kernels_rotate.hip) ---------------------------
+def _orders(ac):
+    return [[(ax + i) % 3 if ac[ax] else i for i in range(3)] for ax in range(3)]
+
+
+def test_planner_offers_the_in_place_rotation_only_where_it_is_one():
+    cube = cd.make_grid_spec((64, 64, 64), (1, 1), _orders((1, 1, 1)))
+    want = {"XToY": 1, "YToZ": 1, "ZToY": -1, "YToX": -1}
+    for op in cd.OPS:
+        p = cd.cudecompExtPlanTranspose(cube, 0, op, inplace=True)
+        assert p.rotate == want[op] and p.n_pack == 1 and p.n_unpack == 1, (op, p.rotate)   # the staged form stays in the plan
+        assert cd.cudecompExtPlanTranspose(cube, 0, op, inplace=False).rotate == 0
+        assert cd.cudecompExtPlanTranspose(cube, 0, op, (1, 0, 0), (1, 0, 0), inplace=True).rotate == 0       # halos
+        assert cd.cudecompExtPlanTranspose(cube, 0, op, None, None, (0, 1, 0), (0, 1, 0), inplace=True).rotate == 0  # padding
+    # not cubic / default layout (same order everywhere: in place is a no-op or a staged copy, never a rotation)
+    for spec in (cd.make_grid_spec((64, 64, 32), (1, 1), _orders((1, 1, 1))), cd.make_grid_spec((64, 64, 64), (1, 1), _orders((0, 0, 0)))):
+        for op in cd.OPS:
+            assert cd.cudecompExtPlanTranspose(spec, 0, op, inplace=True).rotate == 0, (list(spec.gdims), op)
+    # mixed layouts: the hops between two orders that ARE a rotation of each other still qualify (X and Y x-fastest, Z z-fastest)
+    mixed = cd.make_grid_spec((64, 64, 64), (1, 1), _orders((1, 0, 1)))
+    assert [cd.cudecompExtPlanTranspose(mixed, 0, op, inplace=True).rotate for op in cd.OPS] == [0, -1, 1, 0]
+    two = cd.make_grid_spec((64, 64, 64), (2, 1), _orders((1, 1, 1)))
+    assert all(cd.cudecompExtPlanTranspose(two, r, op, inplace=True).rotate == 0 for r in (0, 1) for op in cd.OPS)
+
+
+def test_rotation_restatement_closes_every_orbit():
+    """numpy restatement of rotate_kernel's decomposition (owner = smallest of the three block triples, three tiles loaded,
+    three stored, in-tile transposition of the linear index space) on a small cube, both directions, against the index map
+    of the transposes it replaces: out[y + N*(z + N*x)] = in[x + N*(y + N*z)]."""
+    n, t = 12, 4
+    nb = n // t
+    a = np.arange(n ** 3, dtype=np.int64)
+    old = a.reshape(n, n, n)   # [p2][p1][p0]
+    for fwd in (True, False):
+        new = np.full_like(old, -1)
+        owners = 0
+        for b2 in range(nb):
+            for b1 in range(nb):
+                for b0 in range(nb):
+                    keys = [((b2 * nb + b1) * nb + b0), ((b1 * nb + b0) * nb + b2), ((b0 * nb + b2) * nb + b1)]
+                    if keys[0] > keys[1] or keys[0] > keys[2]:
+                        continue
+                    owners += 1
+                    orbit = [(b0, b1, b2), (b2, b0, b1), (b1, b2, b0)] if fwd else [(b0, b1, b2), (b1, b2, b0), (b2, b0, b1)]
+                    nt = 1 if b0 == b1 == b2 else 3
+                    tiles = [old[c2 * t:(c2 + 1) * t, c1 * t:(c1 + 1) * t, c0 * t:(c0 + 1) * t].copy() for c0, c1, c2 in orbit[:nt]]
+                    for k in range(nt):
+                        src = tiles[(k + 1) % nt].reshape(-1)          # old linear order of the source tile
+                        if fwd:    # old linear = x + T*y -> new linear = y + T^2*x
+                            out = src.reshape(t * t, t).T.reshape(-1)
+                        else:      # old linear = y + T^2*x -> new linear = x + T*y
+                            out = src.reshape(t, t * t).T.reshape(-1)
+                        c0, c1, c2 = orbit[k]
+                        assert (new[c2 * t:(c2 + 1) * t, c1 * t:(c1 + 1) * t, c0 * t:(c0 + 1) * t] == -1).all()
+                        new[c2 * t:(c2 + 1) * t, c1 * t:(c1 + 1) * t, c0 * t:(c0 + 1) * t] = out.reshape(t, t, t)
+        assert owners == (nb ** 3 - nb) // 3 + nb
+        # forward: new[p2][p1][p0] = old at position (p2', p1', p0') = (p1, p0, p2) i.e. new[p0,p1,p2] = old[p2,p0,p1]
+        exp = old.transpose(1, 0, 2) if False else None
+        p2, p1, p0 = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+        if fwd:
+            exp = old[p1, p0, p2]   # old[(q0,q1,q2) = (p2,p0,p1)] -> index [q2][q1][q0] = [p1][p0][p2]
+        else:
+            exp = old[p0, p2, p1]   # old[(q0,q1,q2) = (p1,p2,p0)] -> index [p0][p2][p1]
+        assert np.array_equal(new, exp), fwd
+        # ... and that IS the transpose: X pencil (x,y,z) -> Y pencil (y,z,x): out[y + N*(z + N*x)] = in[x + N*(y + N*z)]
+        if fwd:
+            x, y, z = 3, 7, 10
+            assert new.reshape(-1)[y + n * (z + n * x)] == a[x + n * (y + n * z)]
