@@ -496,6 +496,31 @@ def extras_single_gpu(cd, torch, h, stream):
         out["halo_pencil_transposes"] = {"workload": "transposes onto halo-carrying pencils: 1024^3 fp64, halo (1,1,1) on every pencil, "
                                                      "1x1 grid, out of place, 2 warm-up + 5 timed per op; frac = 2 x 8 GiB / ms / 8 TB/s",
                                          "per_layout": res}
+        # the same on config 5's per-rank pencil shape (2048 x 1024 x 256 fp64, halo 2: 2052-wide rows), axis-contiguous
+        gdims5, halo5 = (2048, 1024, 256), (2, 2, 2)
+        gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims5, (1, 1), axis_contiguous=(1, 1, 1)))
+        nel = max(cd.cudecompGetPencilInfo(h, gd, ax, halo5).size for ax in range(3))
+        a = torch.zeros(nel, dtype=torch.float64, device="cuda")
+        b = torch.zeros(nel, dtype=torch.float64, device="cuda")
+        work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * 8)
+        ops, moved = {}, 2 * 8 * gdims5[0] * gdims5[1] * gdims5[2]
+        for op in cd.OPS:
+            for _ in range(2):
+                cd.cudecompTranspose(op, h, gd, a.data_ptr(), b.data_ptr(), work, cd.DOUBLE, halo5, halo5, None, None, stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                cd.cudecompTranspose(op, h, gd, a.data_ptr(), b.data_ptr(), work, cd.DOUBLE, halo5, halo5, None, None, stream)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            ops[op] = {"ms": round(ms, 4), "frac": round(moved / ms / 1e6 / HBM_PEAK_GBPS, 4), "kernel": cd.cudecompExtLastKernelName()}
+        cd.cudecompFree(h, gd, work)
+        cd.cudecompGridDescDestroy(h, gd)
+        del a, b
+        out["halo_pencil_transposes"]["config5_pencil_contiguous"] = {
+            "workload": "2048 x 1024 x 256 fp64, halo (2,2,2) on every pencil, 1x1 grid, axis-contiguous, out of place; frac = 2 x 4 GiB / ms / 8 TB/s",
+            "per_op": ops}
     except Exception as e:
         out["halo_pencil_transposes"] = {"error": str(e)[:200]}
     return out

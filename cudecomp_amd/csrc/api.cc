@@ -327,7 +327,7 @@ void cudecompCommInfo::release() {
     (void)hipDeviceSynchronize();
     unsigned long long v = 0;
     if (hipMemcpy(&v, dev_epoch, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) high = std::max<uint64_t>(high, v);
-    (void)hipFree(dev_epoch);
+    // (the cell belongs to the handle's slab of epoch cells, transport.cc devEpoch: nothing to free here)
     (void)hipGetLastError();
     dev_epoch = nullptr;
   }

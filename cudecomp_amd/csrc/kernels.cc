@@ -273,8 +273,15 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
         // 16-byte lanes need whole vectors along i only: the windows run over linear positions, whatever the row length
         c.variant = (es < 16 && c.dm.e[0] % (16 / es) == 0) ? 16 / es : 1;
         c.t1 = (unsigned int)((span + ub / es - 1 + tj - 1) / tj);  // windows along the linear positions (+ one unit of phase slack)
-        // tile walk (kernels_lines.hip): groups of 16 tile rows, inside a group one window after the other for all its rows
-        const long long run_kib = tuning ? tuning->lines_run_kib : 0, group = tuning ? tuning->lines_group : 16;
+        // Tile walk (kernels_lines.hip): groups of 16 tile rows; inside a group short runs of 2 KiB per slab (four windows of
+        // 8-byte elements) for all its rows, then the next run -- the source is read plane by plane in whole rows, every
+        // slab's write stream advances steadily.  Wider moves (several groups: more than 1024 slabs) take runs of 32 KiB.
+        // Measured on two boxes, fp64 forward hops onto halo pencils (profiles/r06_tuning.md): 1024^3 halo 1 window kernel
+        // 3.52 ms -> 3.14 (2 KiB; 32 KiB 3.19-3.29, 256 KiB 3.45-3.77); config 5's pencil X->Y (2048 slabs) 1.72-1.77 -> 1.55-1.61
+        // (32 KiB; 2 KiB 1.66), Y->Z (260-element rows) 1.81 -> 1.66 (2 KiB; 32 KiB 1.79-1.86).
+        const long long group = tuning ? tuning->lines_group : 16;
+        const bool several_groups = group > 0 && group < (long long)c.t0;
+        const long long run_kib = (tuning && tuning->lines_run_kib >= 0) ? tuning->lines_run_kib : (several_groups ? 32 : 2);
         const long long run = run_kib > 0 ? std::max<long long>(1, (run_kib << 10) / ((long long)tj * es)) : 1;
         c.p0 = (long long)c.t1 >= 2 * run ? (int)run : 0;
         c.p1 = 1 | 2 | 8;  // XCD-contiguous, along the destination first, "lines"

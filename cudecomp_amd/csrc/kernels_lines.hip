@@ -61,9 +61,10 @@ __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b
     if (lb < (per << 3)) lt = (lb & 7u) * per + (lb >> 3);
   }
   // Walk, outermost to innermost: groups of G tile rows (p1 >> 8; 0 = all of them) -- runs of R windows along l (p0; 0 = the
-  // whole range) -- the tile rows of the group -- the windows of the run.  The default (kernels.cc) is G = 16, R = 1: for one
-  // window after the other, the 16 x TI slabs of the group each get their next TJ elements -- the source is then read in
-  // whole rows, plane by plane, and every slab's write stream advances steadily (measured: profiles/r06_tuning.md).
+  // whole range) -- the tile rows of the group -- the windows of the run.  The default (kernels.cc) is G = 16 with short runs
+  // (2 KiB per slab; 32 KiB when the move has several groups): run after run, the 16 x TI slabs of the group each get their
+  // next piece -- the source is then read in whole rows, plane by plane, and every slab's write stream advances steadily
+  // (measured: profiles/r06_tuning.md).
   unsigned int bi, bl;
   {
     const unsigned int G = (unsigned int)(b.p1[mi] >> 8) ? (unsigned int)(b.p1[mi] >> 8) : ti_n;

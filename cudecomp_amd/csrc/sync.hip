@@ -30,22 +30,25 @@ using u64 = unsigned long long;
 // stages of a staged exchange that have completely landed, kFlagScale-1 = "everything of this call has landed".
 __global__ void epoch_begin_k(u64* epoch, const FlagList begun) {
   // every lane reads the old value before lane 0 bumps it (one wave: the read precedes the write in program order)
-  const u64 e = *epoch + 1;
+  // (system-scope atomics on an uncached cell: no compute die's cache ever holds the counter, see transport.cc devEpoch)
+  const u64 e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
   __builtin_amdgcn_wave_barrier();
-  if (threadIdx.x == 0) *epoch = e;
+  if (threadIdx.x == 0) __hip_atomic_store(epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int i = threadIdx.x;
   if (i < begun.n) __hip_atomic_store(begun.f[i], e * kFlagScale, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void signal_k(const u64* epoch, const FlagList flags, u64 step) {
   const int i = threadIdx.x;
-  if (i < flags.n) __hip_atomic_store(flags.f[i], *epoch * kFlagScale + step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (i < flags.n)
+    __hip_atomic_store(flags.f[i], __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * kFlagScale + step, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void wait_k(const u64* epoch, const FlagList flags, u64* status, long long timeout_ticks, u64 step) {
   const int i = threadIdx.x;
   if (i < flags.n) {
-    const u64 call = *epoch;
+    const u64 call = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const u64 e = call * kFlagScale + step;
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(flags.f[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {

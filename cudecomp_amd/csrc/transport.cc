@@ -128,6 +128,7 @@ class PeerContext {
     for (int p = 0; p < (int)flag_base_.size(); ++p)
       if (p != h_->rank && flag_base_[p]) (void)hipIpcCloseMemHandle(flag_base_[p]);
     if (flag_mem_) (void)hipFree(flag_mem_);
+    if (epoch_slab_) (void)hipFree(epoch_slab_);
     if (verify_count_) (void)hipFree(verify_count_);
     for (hipStream_t s : copy_streams_) (void)hipStreamDestroy(s);
     for (hipEvent_t e : copy_events_) (void)hipEventDestroy(e);
@@ -485,10 +486,26 @@ class PeerContext {
                   "entered the matching call; the results of that exchange are incomplete");
   }
 
-  // device call counter of a communicator (created on first use, starting at the agreed base)
+  // Device call counter of a communicator: one cell per board row (slot) in a slab that lives as long as this context.
+  // The cells used to be a hipMalloc / hipFree per communicator; a communicator created right after another one was
+  // destroyed then got the SAME address back, and with eight processes on one GPU a compute die can keep serving such an
+  // address's previous life: its epoch kernel then counted on from a stale number, this rank's calls
+  // ran one or more numbers behind its peers', and every flag of an EARLIER call of theirs satisfied its waits -- unpacks
+  // ran ahead of the data of whoever was slowest (found by the rank pool of the GPU suite, profiles/r06_epoch_cells.md).
+  // Now: never re-allocated while the handle lives, uncached (no compute-die cache holds them), written and read with
+  // system-scope atomics, and a communicator that takes over a row writes its agreed base into the row's cell.
   u64* devEpoch(cudecompCommInfo& ci) {
     if (!ci.dev_epoch) {
-      CD_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ci.dev_epoch), 256));
+      if (ci.barrier_slot < 0) CD_INTERNAL_ERROR("one-sided exchange on a communicator without a board row");
+      if (!epoch_slab_) {
+        const size_t bytes = (size_t)kSlots * kEpochStride * sizeof(u64);
+        if (hipExtMallocWithFlags(reinterpret_cast<void**>(&epoch_slab_), bytes, hipDeviceMallocUncached) != hipSuccess || !epoch_slab_) {
+          (void)hipGetLastError();
+          CD_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&epoch_slab_), bytes));
+        }
+        CD_CHECK_HIP(hipMemset(epoch_slab_, 0, bytes));
+      }
+      ci.dev_epoch = epoch_slab_ + (size_t)ci.barrier_slot * kEpochStride;
       const u64 base = ci.epoch_base;
       CD_CHECK_HIP(hipMemcpy(ci.dev_epoch, &base, sizeof(base), hipMemcpyHostToDevice));
       // the counter is first touched by a kernel on the CALLER's stream, which need not be ordered behind a synchronous
@@ -813,6 +830,8 @@ class PeerContext {
   std::vector<hipEvent_t> copy_events_;
   std::vector<u64*> flag_base_;  // device-memory flags: base of every rank's flag buffer as mapped here (empty: board mode)
   u64* flag_mem_ = nullptr;      // my own
+  static constexpr int kEpochStride = 8;  // u64 words between the epoch cells of two rows (one 64-byte unit each)
+  u64* epoch_slab_ = nullptr;    // the communicators' device call counters, one cell per board row (see devEpoch)
   struct Parked {
     char* base;
     size_t bytes;

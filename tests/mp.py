@@ -274,6 +274,15 @@ class _Pool:
             except OSError:
                 pass
         self.workers, self.buf = [], []
+        keep = os.environ.get("CUDECOMP_TEST_POOL_KEEP_LOGS")
+        if keep:  # debugging: what every worker printed, job by job
+            try:
+                os.makedirs(keep, exist_ok=True)
+                for name in os.listdir(self.dir):
+                    if name.endswith(".log"):
+                        shutil.copy(os.path.join(self.dir, name), os.path.join(keep, "%s_%s" % (os.path.basename(self.dir), name)))
+            except OSError:
+                pass
         shutil.rmtree(self.dir, ignore_errors=True)
 
 

@@ -216,9 +216,9 @@ def test_lines_kernel_is_chosen_for_forward_hops_onto_halo_pencils_only():
     d = lines_shape(1024, 1024, 1022, 1)
     assert d["cls"] == 1 and d["walk"] & LINES and (d["tile_i"], d["tile_j"], d["access"]) == (64, 64, 4), d
     span = 1021 * 1026 + 1024
-    assert d["tiles_i"] == 16 and d["tiles_j"] == -(-(span + 15) // 64) and d["run"] == 1 and d["walk"] >> 8 == 0, d  # 16 tile rows: one group
+    assert d["tiles_i"] == 16 and d["tiles_j"] == -(-(span + 15) // 64) and d["run"] == 4 and d["walk"] >> 8 == 0, d  # 16 tile rows: one group, runs of 2 KiB
     c5 = lines_shape(2048, 2048, 256, 2)  # config 5's pencil shape on a 1 x 1 grid
-    assert c5["walk"] & LINES and c5["variant"] == 2 and c5["tiles_i"] == 32 and c5["walk"] >> 8 == 16 and c5["run"] == 1, c5
+    assert c5["walk"] & LINES and c5["variant"] == 2 and c5["tiles_i"] == 32 and c5["walk"] >> 8 == 16 and c5["run"] == 64, c5  # two groups: runs of 32 KiB
     for es in (4, 16):
         assert lines_shape(1024, 1024, 64, 1, es=es)["walk"] & LINES
     # without the planner's word the gap cells are not the move's: the window kernel
@@ -236,7 +236,7 @@ def test_lines_kernel_is_chosen_for_forward_hops_onto_halo_pencils_only():
     # small moves stay with the plain tile kernel unless asked (flag 4), like the window kernel
     assert not lines_shape(128, 128, 4, 1)["walk"] & LINES
     small = cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (128, 128, 8), (1, 128, 128 * 128), (130 * 10, 1, 130), flags=WHOLE | 4)
-    assert small["walk"] & LINES and small["run"] == 1, small
+    assert small["walk"] & LINES and small["run"] == 4, small
     # an odd row count along i: element-wise lanes (vectors hold whole elements along i only)
     assert lines_shape(1023, 1024, 64, 1)["variant"] == 1
     assert lines_shape(1024, 1023, 64, 1)["variant"] == 2   # the row length does not matter
