@@ -487,13 +487,13 @@ class PeerContext {
   }
 
   // Device call counter of a communicator: one cell per board row (slot) in a slab that lives as long as this context.
-  // The cells used to be a hipMalloc / hipFree per communicator; a communicator created right after another one was
-  // destroyed then got the SAME address back, and with eight processes on one GPU a compute die can keep serving such an
-  // address's previous life: its epoch kernel then counted on from a stale number, this rank's calls
-  // ran one or more numbers behind its peers', and every flag of an EARLIER call of theirs satisfied its waits -- unpacks
-  // ran ahead of the data of whoever was slowest (found by the rank pool of the GPU suite, profiles/r06_epoch_cells.md).
-  // Now: never re-allocated while the handle lives, uncached (no compute-die cache holds them), written and read with
-  // system-scope atomics, and a communicator that takes over a row writes its agreed base into the row's cell.
+  // The cells used to be a hipMalloc / hipFree per communicator, so a communicator created right after another one was
+  // destroyed got the SAME address back -- and with several processes on one GPU a compute die can keep serving a re-allocated
+  // address's previous life (found on the test programs' data buffers).  A call counter read stale would
+  // put a rank's call numbers out of step with its peers' and let flags of earlier calls satisfy its waits.  Never observed
+  // (round 6 suspected it for a failure that turned out to be a test's own race, profiles/r06_pooled_suite_failure.md); kept
+  // as the sturdier design: never re-allocated while the handle lives, uncached (no compute-die cache holds them), written
+  // and read with system-scope atomics, and a communicator that takes over a row writes its agreed base into the row's cell.
   u64* devEpoch(cudecompCommInfo& ci) {
     if (!ci.dev_epoch) {
       if (ci.barrier_slot < 0) CD_INTERNAL_ERROR("one-sided exchange on a communicator without a board row");
@@ -594,6 +594,29 @@ class PeerContext {
       copy_streams_.push_back(s);
     }
     return copy_streams_[i];
+  }
+
+  bool debug() const { return debug_; }
+  // debugging aid (CUDECOMP_DEBUG_PEER=1): device call counter and the flags of my row, read on the host after a device sync
+  void dumpRow(cudecompCommInfo& ci, const char* when) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(nullptr, &cap);  // (never inside a capture: the dump synchronizes)
+    if (hipGetLastError() != hipSuccess || cap != hipStreamCaptureStatusNone) return;
+    if (hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    unsigned long long e = 0;
+    if (ci.dev_epoch) (void)hipMemcpy(&e, ci.dev_epoch, sizeof(e), hipMemcpyDeviceToHost);
+    char line[512];
+    int n = snprintf(line, sizeof(line), "CUDECOMP:DEBUG rank %d %s slot %d P %d base %llu device epoch %llu ready", h_->rank, when,
+                     ci.barrier_slot, ci.nranks, (unsigned long long)ci.epoch_base, e);
+    if (board_ && ci.barrier_slot >= 0) {
+      const u64* row = reinterpret_cast<const u64*>(board_ + flagRowOff(ci.barrier_slot, h_->rank));
+      n += snprintf(line + n, sizeof(line) - n, " %llu landed", (unsigned long long)row[0]);
+      for (int i = 0; i < landed_n_ && n < 480; ++i) n += snprintf(line + n, sizeof(line) - n, " %llu", (unsigned long long)row[1 + i]);
+    }
+    fprintf(stderr, "%s\n", line);
   }
 
   // highest counter value any rank may have left in row `slot` that involves me
@@ -736,11 +759,11 @@ class PeerContext {
 
   // Where a board is mapped.  The board is registered with HIP and polled by kernels; a process that finalizes a handle and
   // creates another (a job server, a long-lived test worker) would normally get the NEW board at the address the old one
-  // had -- and on this platform a compute die can keep serving the old translation of a recycled address (the family of
-  // profiles/r05_stale_xcd_view.md; round 6: wait kernels of a re-created handle read the flags of its predecessor's board
-  // and let unpacks run ahead of their data, profiles/r06_board_address_reuse.md).  So boards are placed in a reserved
-  // address arena, each at a fresh address, and a retired board's range stays reserved: no board address is ever used twice
-  // by a process.  CUDECOMP_BOARD_FRESH_ADDRESS=0 restores plain mmap (debugging).
+  // had.  Given what this platform does with recycled addresses when several processes share a GPU
+  // boards are placed in a reserved address arena, each at a fresh address, and a retired board's range stays reserved: no
+  // board address is ever used twice by a process.  A precaution, not the fix of an observed failure (round 6 suspected a
+  // recycled board for a failure that was a test's own race: arms with and without the arena failed alike,
+  // profiles/r06_pooled_suite_failure.md).  CUDECOMP_BOARD_FRESH_ADDRESS=0 restores plain mmap.
   static constexpr size_t kArenaBytes = (size_t)4 << 30, kArenaAlign = (size_t)2 << 20;
   static char*& arenaBase() {
     static char* base = nullptr;
@@ -1354,6 +1377,7 @@ PeerCall peerBegin(cudecompHandle_t h, cudecompCommInfo& ci, bool rendezvous, co
     call.direct = false;
   }
   call.epoch = pc.devEpoch(ci);
+  if (pc.debug()) pc.dumpRow(ci, "begin");  // CUDECOMP_DEBUG_PEER=1 (host-synchronous): the row's counters as this call finds them
   FlagList begun;  // "my call has begun": where each member polls it (device flags) / my board cell (board mode)
   if (pc.deviceFlags()) {
     // (my own buffer too: a one-member communicator in the self-exchange test mode waits for itself)

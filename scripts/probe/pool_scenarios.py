@@ -21,10 +21,16 @@ def main():
         n, (pr, pc), backend = int(parts[0]), map(int, parts[1].split("x")), int(parts[2][1:])
         body = parts[3] if len(parts) > 3 else "graph"
         args = {"gdims": (96, 80, 112), "pdims": (pr, pc), "kind": 1, "ac": (1, 1, 1), "transpose_backend": backend, "replays": 2}
-        fn = {"graph": "graph_cycle", "cycle": "cycle_exact", "chain": "transpose_chain"}[body]
+        variant = None
+        if body.startswith("graph-"):   # graph-nc (no capture), graph-td (torch data pencils), graph-ds (default stream)
+            body, variant = "graph", body[6:]
+            args[{"nc": "no_capture", "td": "torch_data", "ds": "default_stream"}[variant]] = True
+        fn = {"graph": "graph_cycle", "cycle": "cycle_exact", "chain": "transpose_chain", "probe": "pool_probe"}[body]
+        if body == "probe":  # processes with a GPU context, no library handle
+            args = {"handle": False}
         try:
             res = mp.run_ranks(n, "tests.gpu_bodies", fn, args, timeout=120, extra_env=env)
-            fails = [f[:150] for r in res for f in (r if isinstance(r, list) else r["failures"])]
+            fails = [f[:150] for r in res for f in (r if isinstance(r, list) else r.get("failures", []))]
         except AssertionError as e:
             fails = ["launch failed: " + str(e)[-300:]]
         out["results"].append({"job": spec, "failures": len(fails), "first": fails[:2]})

@@ -3,7 +3,7 @@ correct?  The rank pool of tests/mp.py makes the GPU suite do exactly that; its 
 (graph_cycle, 1 x 4 grid, after three 2 x 2 jobs on the same handle).  Arms: the same job sequence in FRESH processes through
 the `many` runner (handle reuse only), and through the pool with eight workers alive (handle reuse + idle contexts + worlds
 rebuilt inside living processes).  usage: python scripts/probe/pool_sequence_stress.py [repetitions] [pool|fresh|both] [K=V ...]
-(K=V: CUDECOMP_* switches for the pooled jobs, e.g. CUDECOMP_BOARD_FRESH_ADDRESS=0 to see the failure the address arena fixed)"""
+(K=V: CUDECOMP_* switches for the pooled jobs; what the failure turned out to be: profiles/r06_pooled_suite_failure.md)"""
 import json
 import os
 import sys

@@ -11,10 +11,14 @@ import cudecomp_amd as cd
 
 def main():
     torch.cuda.set_device(0)
+    pre = bool(os.environ.get("WALK_AB_PREALLOCATE"))
+    if pre:  # as in bench.py: the caching allocator has served (and keeps) large blocks before these buffers are carved out
+        big = [torch.zeros(1 << 30, dtype=torch.float64, device="cuda") for _ in range(3)]
+        del big
     h = cd.cudecompInit()
     st = torch.cuda.current_stream().cuda_stream
     out = {"walk": os.environ.get("CUDECOMP_TILE_WALK", "default"), "cases": {},
-           "switches": {k: v for k, v in os.environ.items() if k.startswith("CUDECOMP_LINES") or k == "CUDECOMP_PRESERVE_OUTPUT_HALOS"}}
+           "preallocate": pre, "switches": {k: v for k, v in os.environ.items() if k.startswith("CUDECOMP_LINES") or k == "CUDECOMP_PRESERVE_OUTPUT_HALOS"}}
     for name, gdims, halo in (("1024^3 halo 1", (1024, 1024, 1024), (1, 1, 1)), ("2048x1024x256 halo 2", (2048, 1024, 256), (2, 2, 2))):
         gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims, (1, 1), axis_contiguous=(1, 1, 1)))
         nel = max(cd.cudecompGetPencilInfo(h, gd, ax, halo).size for ax in range(3))

@@ -198,6 +198,18 @@ def pytest_runtest_protocol(item, nextitem):
     return True
 
 
+# modules whose tests start GPU processes by themselves (subprocess / mpirun, not through tests/mp.py): the rank pool must be
+# gone before they do (at most eight processes on the device)
+_DIRECT_LAUNCHERS = ("test_gpu_fft3d", "test_gpu_c_example", "test_gpu_mpi_flavour", "test_fortran", "test_gpu_perf_report")
+
+
+def pytest_runtest_setup(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if name in _DIRECT_LAUNCHERS:
+        from tests import mp
+        mp.pool_stop()
+
+
 def pytest_sessionfinish(session, exitstatus):
     if _child[0] is not None:
         _child[0].close()

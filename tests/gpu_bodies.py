@@ -419,13 +419,22 @@ def graph_cycle(rank, nranks, args):
     pin = [cd.cudecompGetPencilInfo(h, gd, ax) for ax in range(3)]
     nel = max(p.size for p in pin)
     work = cd.cudecompMalloc(h, gd, cd.cudecompGetTransposeWorkspaceSize(h, gd) * es)
-    ta, pa = G.library_bytes(cd, h, gd, nel * es)
-    tb, pb = G.library_bytes(cd, h, gd, nel * es)
-    tz, pz = G.library_bytes(cd, h, gd, nel * es)  # keeps a copy of the Z pencil of every cycle
+    if args.get("torch_data"):  # (bisecting aid: data pencils from torch instead of cudecompMalloc)
+        ta, tb, tz = (torch.zeros(nel * es, dtype=torch.uint8, device="cuda") for _ in range(3))
+        pa = pb = pz = None
+    else:
+        ta, pa = G.library_bytes(cd, h, gd, nel * es)
+        tb, pb = G.library_bytes(cd, h, gd, nel * es)
+        tz, pz = G.library_bytes(cd, h, gd, nel * es)  # keeps a copy of the Z pencil of every cycle
     a, b, z = ta.view(idt), tb.view(idt), tz.view(idt)
     x0 = expected_pencil_words(pin[0], gdims, es)
     z0 = expected_pencil_words(pin[2], gdims, es)
-    stream = torch.cuda.Stream()
+    stream = torch.cuda.current_stream() if args.get("default_stream") else torch.cuda.Stream()
+    # x0 / z0 (and the zero fills of torch buffers) were produced on the DEFAULT stream; a torch side stream is not ordered
+    # behind it by itself.  Round 6: without this line the first assignment below could read x0 before its kernels had run --
+    # it then copied what the block held before (the previous job's pencil, when the allocator reused the block), the rank's
+    # whole contribution to the cycle was wrong, and the failure looked like a missed flag (profiles/r06_pooled_suite_failure.md).
+    stream.wait_stream(torch.cuda.current_stream())
     failures = []
 
     def cycle(sptr):
@@ -446,9 +455,10 @@ def graph_cycle(rank, nranks, args):
                             % (rank, bad_x.numel(), bad_x[:3].tolist(), bad_z.numel(), bad_z[:3].tolist(),
                                z[bad_z[:3]].tolist() if bad_z.numel() else []))
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-        cycle(torch.cuda.current_stream().cuda_stream)
-    for it in range(args.get("replays", 3)):
+    if not args.get("no_capture"):
+        with torch.cuda.graph(graph, stream=None if args.get("default_stream") else stream, capture_error_mode="thread_local"):
+            cycle(torch.cuda.current_stream().cuda_stream)
+    for it in range(0 if args.get("no_capture") else args.get("replays", 3)):
         shift = 1000003 * (it + 1)
         with torch.cuda.stream(stream):
             a[:x0.numel()] = x0 + shift
@@ -465,7 +475,8 @@ def graph_cycle(rank, nranks, args):
     torch.cuda.synchronize()
     del a, b, z, ta, tb, tz
     for p in (pa, pb, pz):
-        cd.cudecompFree(h, gd, p)
+        if p is not None:
+            cd.cudecompFree(h, gd, p)
     cd.cudecompFree(h, gd, work)
     cd.cudecompGridDescDestroy(h, gd)
     return {"failures": failures, "counters": counters}

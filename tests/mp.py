@@ -508,12 +508,12 @@ def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
     return logs
 
 
-def run_binary_groups(jobs, max_ranks=8):
+def run_binary_groups(jobs, max_ranks=8, collect_errors=False):
     """Several INDEPENDENT native launches side by side -- jobs = [(nranks, argv, timeout, extra_env), ...] -- as long as
     together they stay within `max_ranks` processes on the GPU (the device serves eight processes without time-slicing them,
     DESIGN.md section 9).  The test programs spend most of their time on the host (filling and comparing pencils, the control
     plane of a descriptor per case), so two four-rank groups take about as long as one.  Returns the per-job logs in order;
-    raises the first failure after all jobs have ended."""
+    raises the first failure after all jobs have ended (collect_errors: returns the AssertionError in the job's place)."""
     from concurrent.futures import ThreadPoolExecutor
     pool_stop()
     results, errors = [None] * len(jobs), []
@@ -529,6 +529,7 @@ def run_binary_groups(jobs, max_ranks=8):
                     results[i] = f.result()
                 except AssertionError as e:
                     errors.append(e)
+                    results[i] = e
         batch.clear()
 
     for i, job in enumerate(jobs):
@@ -538,6 +539,6 @@ def run_binary_groups(jobs, max_ranks=8):
         batch.append((i, job))
         used += job[0]
     flush()
-    if errors:
+    if errors and not collect_errors:
         raise errors[0]
     return results

@@ -47,8 +47,10 @@ def test_fft3d_slab_shortcuts_agree_with_the_plain_passes(nranks, pr, pc, expect
     real-to-complex flavour (:238-330), whose decomposed grid is (gx/2+1) x gy x gz."""
     base = ["--gx", "64", "--gy", "60", "--gz", "68", "--pr", str(pr), "--pc", str(pc), "--backend", "8" if nranks > 1 else "4",
             "--warmup", "1", "--trials", "2"] + prec + mode
-    on, _ = run_fft3d.run(nranks, base)
-    off, _ = run_fft3d.run(nranks, base + ["--no-slab-opt"])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=2) as ex:  # the two runs side by side: at most 2 x 4 ranks on the GPU
+        f_on, f_off = ex.submit(run_fft3d.run, nranks, base), ex.submit(run_fft3d.run, nranks, base + ["--no-slab-opt"])
+        (on, _), (off, _) = f_on.result(), f_off.result()
     assert on["ok"] and off["ok"], (on, off)
     assert on["slab"] == expect and off["slab"] == "none", (on["slab"], off["slab"])
     assert on["mode"] == ("r2c" if mode else "c2c") and on["spectrum_checked"] and off["spectrum_checked"]
