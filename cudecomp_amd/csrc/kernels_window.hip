@@ -74,12 +74,22 @@ __global__ __launch_bounds__(NT) void transpose_window_kernel(const Batch b) {
     const int li = (tid % TPR) * VW, lj = tid / TPR;
     const E* base = src + (jb + lj) * sj + i0 + li;
     V regs[NP] = {};
+    if (interior) {
+      // (its own copy of the loop: with the edge test of the other branch folded in, the compiler waited for single loads
+      // between the passes; here all NP loads of a lane are in flight before the first use)
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int jj = lj + p * RPP;
-      const long long j = jb + jj;
-      if (jj < ROWS && (interior || (i0 + li < ei && j >= 0 && j < ej)))
-        regs[p] = loadVec<loadsStream<STREAM>(), ES * VW>(base + (long long)(p * RPP) * sj);
+      for (int p = 0; p < NP; ++p) {
+        const int jj = lj + p * RPP;
+        if (jj < ROWS) regs[p] = loadVec<loadsStream<STREAM>(), ES * VW>(base + (long long)(p * RPP) * sj);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int jj = lj + p * RPP;
+        const long long j = jb + jj;
+        if (jj < ROWS && i0 + li < ei && j >= 0 && j < ej)
+          regs[p] = loadVec<loadsStream<STREAM>(), ES * VW>(base + (long long)(p * RPP) * sj);
+      }
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {

@@ -19,8 +19,19 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     out = {"walk": os.environ.get("CUDECOMP_TILE_WALK", "default"), "cases": {},
            "preallocate": pre, "switches": {k: v for k, v in os.environ.items() if k.startswith("CUDECOMP_LINES") or k == "CUDECOMP_PRESERVE_OUTPUT_HALOS"}}
-    for name, gdims, halo in (("1024^3 halo 1", (1024, 1024, 1024), (1, 1, 1)), ("2048x1024x256 halo 2", (2048, 1024, 256), (2, 2, 2))):
-        gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims, (1, 1), axis_contiguous=(1, 1, 1)))
+    park = int(os.environ.get("WALK_AB_PARK_GIB", "0"))
+    if park:  # as in bench.py: the library's workspace pool holds the main cycle's pencils and workspace when the extras run
+        gd0 = cd.cudecompGridDescCreate(h, cd.make_config((64, 64, 64), (1, 1)))
+        ptrs = [cd.cudecompMalloc(h, gd0, (park << 30) // 4), cd.cudecompMalloc(h, gd0, (park << 30) // 4), cd.cudecompMalloc(h, gd0, (park << 30) // 2)]
+        for q in ptrs:
+            cd.cudecompFree(h, gd0, q)
+        cd.cudecompGridDescDestroy(h, gd0)
+    out["park_gib"] = park
+    cases = [("1024^3 halo 1", (1024, 1024, 1024), (1, 1, 1), (1, 1, 1)), ("2048x1024x256 halo 2", (2048, 1024, 256), (2, 2, 2), (1, 1, 1))]
+    if os.environ.get("WALK_AB_DEFAULT_FIRST"):  # bench.py measures the default layout on the same shapes first
+        cases.insert(0, ("1024^3 halo 1 default layout", (1024, 1024, 1024), (1, 1, 1), (0, 0, 0)))
+    for name, gdims, halo, ac in cases:
+        gd = cd.cudecompGridDescCreate(h, cd.make_config(gdims, (1, 1), axis_contiguous=ac))
         nel = max(cd.cudecompGetPencilInfo(h, gd, ax, halo).size for ax in range(3))
         a = torch.zeros(nel, dtype=torch.float64, device="cuda")
         b = torch.zeros(nel, dtype=torch.float64, device="cuda")

@@ -11,6 +11,8 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "suite_order(n): position of a GPU test inside its module's slot of the suite order")
+    config.addinivalue_line("markers", "extended: long arms that are not part of the default -m gpu run (CUDECOMP_TEST_EXTENDED=1 runs them; "
+                                       "their logs go to profiles/)")
 
 
 def pytest_sessionstart(session):
@@ -83,6 +85,11 @@ _ORDER = ["test_gpu_kernels", "test_gpu_dense_rows", "test_gpu_transpose", "test
 
 
 def pytest_collection_modifyitems(session, config, items):
+    if not os.environ.get("CUDECOMP_TEST_EXTENDED"):
+        skip = pytest.mark.skip(reason="extended arm: set CUDECOMP_TEST_EXTENDED=1")
+        for item in items:
+            if item.get_closest_marker("extended") is not None:
+                item.add_marker(skip)
     if os.environ.get("CUDECOMP_TEST_KEEP_ORDER"):
         return
     rank = {m: i for i, m in enumerate(_ORDER)}

@@ -29,9 +29,12 @@ CONFIGS = [
 
 
 @pytest.mark.parametrize("name,nranks,args", CONFIGS, ids=[c[0] for c in CONFIGS])
-@pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_MPI_P2P, cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_NVSHMEM_SM],
+@pytest.mark.parametrize("backend", [pytest.param(cd.TRANSPOSE_COMM_MPI_P2P, marks=pytest.mark.extended),
+                                     pytest.param(cd.TRANSPOSE_COMM_NVSHMEM_PL, marks=pytest.mark.extended), cd.TRANSPOSE_COMM_NVSHMEM_SM],
                          ids=["peer_copy", "peer_pipelined", "peer_put"])
 def test_full_size_cycle_properties(name, nranks, args, backend):
+    # (a second kind of payload next to test_full_size_every_cell, which runs every transport: one transport in the default run,
+    # the other two with CUDECOMP_TEST_EXTENDED=1 -- profiles/r06_gpu_suite_extended.log)
     res = run_ranks(nranks, "tests.gpu_bodies", "cycle_properties", dict(args, transpose_backend=backend), timeout=600)
     assert all(r["round_trip_exact"] for r in res)
     totals = [sum(r["sums"][hop] for r in res) for hop in range(5)]

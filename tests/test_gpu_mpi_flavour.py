@@ -87,15 +87,13 @@ def _run_mpi_jobs(jobs):
         return list(ex.map(lambda j: _run_mpi(*j), jobs))
 
 
-def test_mpi_flavour_transposes_over_the_reference_matrix():
-    """MPI_P2P (1), MPI_P2P_PL (2), MPI_A2A (3): >= 500 cases, every one through csrc/bootstrap_mpi.cc:mpiAlltoall."""
-    _need()
+def _transposes(thin):
     configs = load_cases()
     jobs, labels = [], []
     for config, step in sorted(TRANSPOSE_STEP.items()):
         lines = [l for l in configs[config] if _backend(l) in (1, 2, 3)]
         for k, dtype in enumerate(_dtypes(config)):
-            jobs.append(("transpose_test_" + dtype, lines[k % step::step]))
+            jobs.append(("transpose_test_" + dtype, lines[k % step::step][::thin]))
             labels.append((config, dtype))
     total = through_mpi = 0
     for (config, dtype), (binary, pick), text in zip(labels, jobs, _run_mpi_jobs(jobs)):
@@ -103,21 +101,39 @@ def test_mpi_flavour_transposes_over_the_reference_matrix():
         assert n > 0, "%s %s: no transpose took the MPI path" % (config, dtype)
         total += len(pick)
         through_mpi += n
-    assert total >= 500, total
     assert through_mpi >= 4 * total  # 4 ranks x (at least 2 exchanging hops of 4) x ... per case, summed over ranks
+    return total
 
 
-def test_mpi_flavour_halos_over_the_reference_matrix():
-    """HALO_COMM_MPI (1) and HALO_COMM_MPI_BLOCKING (2) through csrc/bootstrap_mpi.cc:mpiHaloExchange."""
-    _need()
+def _halos(thin):
     configs = load_cases()
     jobs = []
     for config, step in sorted(HALO_STEP.items()):
         lines = [l for l in configs[config] if _backend(l) in (1, 2)]
         for k, dtype in enumerate(_dtypes(config)):
-            jobs.append(("halo_test_" + dtype, lines[k % step::step]))
+            jobs.append(("halo_test_" + dtype, lines[k % step::step][::thin]))
     _run_mpi_jobs(jobs)
-    assert sum(len(j[1]) for j in jobs) >= 250
+    return sum(len(j[1]) for j in jobs)
+
+
+def test_mpi_flavour_transposes_over_the_reference_matrix():
+    """MPI_P2P (1), MPI_P2P_PL (2), MPI_A2A (3), every case through csrc/bootstrap_mpi.cc:mpiAlltoall: every second case of the
+    slice in the default run (>= 250), the whole slice (>= 500) in the extended one."""
+    _need()
+    assert _transposes(2) >= 250
+
+
+def test_mpi_flavour_halos_over_the_reference_matrix():
+    """HALO_COMM_MPI (1) and HALO_COMM_MPI_BLOCKING (2) through csrc/bootstrap_mpi.cc:mpiHaloExchange."""
+    _need()
+    assert _halos(2) >= 125
+
+
+@pytest.mark.extended
+def test_mpi_flavour_whole_slices():
+    _need()
+    assert _transposes(1) >= 500
+    assert _halos(1) >= 250
 
 
 def test_mpi_flavour_gpu_aware_path():

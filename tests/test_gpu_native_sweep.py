@@ -172,8 +172,9 @@ def test_sweep_flags_in_device_memory():
 
 
 def _switch_sweep(env):
+    every = 6 if os.environ.get("CUDECOMP_TEST_EXTENDED") else 9  # memory-order pairs of the slice: 4 (6 in the extended run) of 36
     lines = [_tcase(pr, pc, b, extra=mo, oop=oop) for (pr, pc), b, mo, oop in
-             itertools.product(PDIMS, [1, 2, 7, 8], _mem_orders()[::6], (True, False))]
+             itertools.product(PDIMS, [1, 2, 7, 8], _mem_orders()[::every], (True, False))]
     lines += [_tcase(pr, pc, b, hx="1 1 1", hy="1 1 1", hz="1 1 1", px="1 1 1", pz="1 1 1",
                      extra="--acx 1 --acy 1 --acz 1", oop=oop) for (pr, pc), b, oop in itertools.product(PDIMS, (2, 8), (True, False))]
     lines += [_tcase(pr, pc, 8, hx="2 1 1", hy="1 2 1", hz="1 1 2", extra=mo + " -m", oop=True)   # direct put onto halo-shifted rows
