@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b
   constexpr int TPO = TJ / VW;          // lanes per destination window
   constexpr int RPO = kThreads / TPO;   // slabs per store pass
   constexpr int NPO = TI / RPO;
-  static_assert(kThreads % TPR == 0 && kThreads % TPO == 0 && TI % RPO == 0 && TJ % U == 0, "lines mapping");
+  static_assert(kThreads % TPR == 0 && kThreads % TPO == 0 && TI % RPO == 0 && TJ % U == 0 && NP <= 64, "lines mapping");
   __shared__ __attribute__((aligned(16))) E tile[ROWS * PITCH];
 
   int mi;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b
       j = l - k * dk;
     }
     V regs[NP] = {};
-    unsigned int gap_passes = 0;  // passes in which this lane's LDS row is a gap row
+    unsigned long long gap_passes = 0;  // passes in which this lane's LDS row is a gap row (NP is up to 40: element-wise lanes)
     if (interior) {
       // Interior tiles (nearly all): NO per-lane control flow around the loads -- a gap row loads the row's last interior
       // cell instead (a valid address; replaced below), so that the NP loads of a lane are all in flight before the first use.
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b
         const int jc = gap ? ej - 1 : j;
         if (jj < ROWS) {
           regs[p] = loadVec<loadsStream<STREAM>(), ES * VW>(src + (long long)k * sk + (long long)jc * sj + i0 + li);
-          if (gap) gap_passes |= 1u << p;
+          if (gap) gap_passes |= 1ull << p;
         }
         j += RPP;
         if (j >= dk) {  // (dk >= ROWS: at most one row end per tile)
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b
         const int jj = lj + p * RPP;
         if (jj < ROWS && i0 + li < ei && l >= 0 && l < L) {
           if (j < ej) regs[p] = loadVec<loadsStream<STREAM>(), ES * VW>(src + (long long)k * sk + (long long)j * sj + i0 + li);
-          else gap_passes |= 1u << p;
+          else gap_passes |= 1ull << p;
         }
         l += RPP;
         j += RPP;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void transpose_lines_kernel(const Batch b
     if (gap_passes) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        if (gap_passes >> p & 1u) {
+        if (gap_passes >> p & 1ull) {
           const int jj = lj + p * RPP;
           const int lg = lb0 + jj;
           E* row = tile + jj * PITCH + li;

@@ -69,9 +69,19 @@ __global__ __launch_bounds__(kThreads) void rotate_kernel(char* base, int n, int
   // ---- all loads of the orbit first (registers), in the tiles' own linear order: lane vector v covers local linear
   //      lin = VW * (tid + kThreads * v) = c0 + T*c1 + T^2*c2
   V regs[3][NV];
+  // (one straight-line block per case: all 3 * NV loads of an orbit are issued before anything waits)
+  if (single) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    if (t < nt) {
+    for (int v = 0; v < NV; ++v) {
+      const int lin = VW * (tid + kThreads * v);
+      const int c0 = lin % T, c1 = (lin / T) % T, c2 = lin / (T * T);
+      regs[0][v] = loadVec<true, ES * VW>(p + org[0] + c0 + N * c1 + N2 * c2);
+      regs[1][v] = regs[0][v];
+      regs[2][v] = regs[0][v];
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int lin = VW * (tid + kThreads * v);
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void rotate_kernel(char* base, int n, int
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int lin = VW * (tid + kThreads * v);
-        const V val = single ? regs[0][v] : regs[(t + 1) % 3][v];  // (a select of two registers, not an indexed access)
+        const V val = regs[(t + 1) % 3][v];  // (a diagonal tile holds its own content in all three sets)
         if constexpr (FWD) {  // old linear = x + T*y, vector along x: VW scalars a row apart
           const int x = lin % T, y = lin / T;
 #pragma unroll
