@@ -35,6 +35,7 @@ struct Classified {
   bool window = false;   // transposes: destination rows off the 64-byte grid -> transpose_window_kernel (rows: rows_shifted_kernel)
   bool dense = false;    // rows, with window: whole lines across the row ends (rows_dense_kernel)
   bool lines = false;    // transposes, with window: windows over the linear positions of adjacent rows (transpose_lines_kernel)
+  bool rowlines = false; // transposes, with window: the tile's own rows are the adjacent ones (transpose_rowlines_kernel)
   int unit = 0;          // ... and its alignment unit in bytes
   unsigned int t0, t1;
   unsigned long long blocks;
@@ -291,6 +292,21 @@ Classified classify(const Move3D& in, void* const bufs[3], int es, const KernelT
 #endif
         c.blocks = (unsigned long long)c.t0 * c.t1;
       }
+      // ... and the other orientation: the tile's OWN rows i are the adjacent ones (inverse hops of the cycle, unpack-side
+      // permutations; batch planes far apart).  The line at the end of row i holds the gap and the head of row i + 1 -- the
+      // same tile column of the next row: a row's last window runs on into it (transpose_rowlines_kernel, kernels_rowlines.hip).
+      const long long ei = c.dm.e[0], di = c.dm.ds[0], rgap = di - ej;
+      if (!c.lines && planned_row == ej && di == in.dst_row_pitch && rgap > 0 && rgap * es <= kDenseMaxGapBytes && rgap * 8 <= ej &&
+          ej > 2 * (tj + ub / es) && ei >= 2 && ei < (1ll << 30) && di < (1ll << 30) && (ek == 1 || dk >= (ei - 1) * di + ej) &&
+          ub == 128) {
+        c.rowlines = true;
+        c.unit = ub;
+        c.variant = (es < 16 && ei % (16 / es) == 0) ? 16 / es : 1;
+        c.t1 = (unsigned int)((di - 1 + ub / es - 1) / tj + 1);  // windows per row: through the one that holds the last gap cell
+        c.p0 = 0;
+        c.p1 = 1 | 2 | 16;  // XCD-contiguous, windows first, "row lines"
+        c.blocks = (unsigned long long)c.t0 * c.t1 * (unsigned long long)ek;
+      }
     }
     return c;
   }
@@ -325,8 +341,8 @@ void tileOf(int es, int variant, bool window, int* ti, int* tj) {
   }
 }
 
-void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bool window, bool dense, int lines_unit, int es,
-                 const Batch& b, unsigned int blocks, hipStream_t stream) {
+void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bool window, bool dense, int lines_unit, bool rowlines,
+                 int es, const Batch& b, unsigned int blocks, hipStream_t stream) {
   // what ran last, in the words of the kernel templates (bench.py reports its dominant kernel from here)
   int ti = 0, tj = 0;
   tileOf(es, variant, window, &ti, &tj);
@@ -335,6 +351,9 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
   else if (cls == MOVE_ROWS_VEC)
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d>", window ? "rows_shifted_kernel" : "rows_kernel",
              variant, stream_access == 3 ? 3 : (stream_access >= 1 ? 1 : 0));
+  else if (cls == MOVE_TRANSPOSE && rowlines)
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_rowlines_kernel<%d,%d,%d,%d,%d,%d>", es, variant % 100, ti, tj,
+             (stream_access == 2 || stream_access == 4) ? 4 : 0, lines_unit);
   else if (cls == MOVE_TRANSPOSE && lines_unit)
     snprintf(g_last_kernel, sizeof(g_last_kernel), "transpose_lines_kernel<%d,%d,%d,%d,%d,%d>", es, variant % 100, ti, tj,
              (stream_access == 2 || stream_access == 4) ? 4 : 0, lines_unit);
@@ -351,7 +370,8 @@ void launchBatch(MoveClass cls, int variant, int stream_access, bool swizzle, bo
       launchRowsBatch(dense ? 2 : (window ? 1 : 0), variant, stream_access, b, blocks, stream);
       break;
     case MOVE_TRANSPOSE:
-      if (lines_unit) launchLinesBatch(es, variant % 100, stream_access, lines_unit, b, blocks, stream);
+      if (rowlines) launchRowLinesBatch(es, variant % 100, stream_access, b, blocks, stream);
+      else if (lines_unit) launchLinesBatch(es, variant % 100, stream_access, lines_unit, b, blocks, stream);
       else if (window) launchWindowBatch(es, variant % 100, variant >= 100, stream_access, b, blocks, stream);
       else if (es == 4) launchTransposeBatch4(variant, stream_access, swizzle, b, blocks, stream);
       else if (es == 8) launchTransposeBatch8(variant, stream_access, swizzle, b, blocks, stream);
@@ -400,7 +420,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
     for (size_t j = i; j < cs.size() && b.n < kMaxBatch; ++j) {
       if (done[j] || cs[j].cls != cs[i].cls || cs[j].variant != cs[i].variant || cs[j].stream != cs[i].stream ||
           cs[j].swizzle != cs[i].swizzle || cs[j].window != cs[i].window || cs[j].dense != cs[i].dense ||
-          cs[j].lines != cs[i].lines || cs[j].unit != cs[i].unit)
+          cs[j].lines != cs[i].lines || cs[j].unit != cs[i].unit || cs[j].rowlines != cs[i].rowlines)
         continue;
       if (blocks + cs[j].blocks > 0x7fffffffULL) {
         if (b.n == 0) CD_NOT_SUPPORTED("single block move too large for one launch");
@@ -431,8 +451,8 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
         blocks = widest * b.n;
       }
     }
-    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, cs[i].swizzle, cs[i].window, cs[i].dense, cs[i].lines ? cs[i].unit : 0, es, b,
-                (unsigned int)blocks, stream);
+    launchBatch(cs[i].cls, cs[i].variant, cs[i].stream, cs[i].swizzle, cs[i].window, cs[i].dense,
+                (cs[i].lines || cs[i].rowlines) ? cs[i].unit : 0, cs[i].rowlines, es, b, (unsigned int)blocks, stream);
     if (stats) stats->launches[cs[i].cls] += 1;
   }
 }

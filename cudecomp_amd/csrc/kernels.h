@@ -50,7 +50,7 @@ void launchMoves(const Move3D* moves, int n, void* const bufs[3], int es, hipStr
 
 // How a move WOULD run (no launch, no device needed): class, kernel variant, tile, tile counts, walk parameters, access mode.
 // out[10] = {class, variant, tile_i (row copies: 0 plain / 1 shifted / 2 dense kernel), tile_j, tiles_i, tiles_j, batch, p0 (run length), p1 (walk bits: 1 XCD-contiguous, 2 j first,
-// 4 runs over batch planes, 8 transpose_lines_kernel), access mode}.  (Tests of the planning logic: tests/test_kernel_plan.py.)
+// 4 runs over batch planes, 8 transpose_lines_kernel, 16 transpose_rowlines_kernel), access mode}.  (Tests of the planning logic: tests/test_kernel_plan.py.)
 void describeMove(const Move3D& m, const void* src, void* dst, int es, const KernelTuning* tuning, long long out[10]);
 
 // name (template spelling) of the data-movement kernel launched last by this process, "" before the first launch

