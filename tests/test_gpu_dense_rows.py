@@ -119,9 +119,11 @@ def test_transposes_onto_halo_pencils_every_byte_single_rank(kind):
     # transpose_rowlines_kernel (halos of one cell everywhere; fp32 rows hold fewer than two of its windows + a unit: window kernel)
     if kind != 0:
         args = {"gdims": (176, 200, 168), "pdims": (1, 1), "kind": kind, "ac": (1, 1, 1), "halos": [(1, 1, 1)] * 3, "pads": [(0, 0, 0)] * 3,
+                "out_of_place": [True],
                 "expect_kernel": {"XToY": "transpose_lines_kernel", "YToZ": "transpose_lines_kernel",
                                   "ZToY": "transpose_rowlines_kernel", "YToX": "transpose_rowlines_kernel"}}
         assert B.transpose_every_byte(0, 1, args) == []
+        assert B.transpose_every_byte(0, 1, dict(args, out_of_place=[False], expect_kernel=None)) == []  # in place: staged through the workspace
 
 
 @pytest.mark.parametrize("backend", [cd.TRANSPOSE_COMM_MPI_P2P, cd.TRANSPOSE_COMM_NVSHMEM_PL, cd.TRANSPOSE_COMM_NVSHMEM],
@@ -135,6 +137,13 @@ def test_transposes_onto_halo_pencils_every_byte_four_ranks(backend):
         jobs.append({"fn": "transpose_every_byte", "id": "%dx%dx%d" % gdims,
                      "args": {"gdims": gdims, "pdims": (2, 2), "kind": 1, "halos": list(halos), "pads": list(pads),
                               "transpose_backend": backend, "expect_kernel": expect}})
+    # a 1 x 4 slab grid in the axis-contiguous layout with halos everywhere: X <-> Y is LOCAL on every rank (whole-line permutation
+    # kernels: lines forward, row lines back), Y <-> Z exchanges among the four
+    expect = {"XToY": "transpose_lines_kernel", "YToX": "transpose_rowlines_kernel"} if backend != cd.TRANSPOSE_COMM_NVSHMEM_PL else None
+    slab = {"gdims": (200, 176, 96), "pdims": (1, 4), "kind": 1, "ac": (1, 1, 1), "halos": [(1, 1, 1)] * 3, "pads": [(0, 0, 0)] * 3,
+            "transpose_backend": backend}
+    jobs.append({"fn": "transpose_every_byte", "id": "slab_1x4_contiguous", "args": dict(slab, out_of_place=[True], expect_kernel=expect)})
+    jobs.append({"fn": "transpose_every_byte", "id": "slab_1x4_contiguous_in_place", "args": dict(slab, out_of_place=[False])})
     for failures in run_ranks(4, "tests.gpu_bodies", "many", {"jobs": jobs}, timeout=600):
         assert failures == []
 
@@ -302,7 +311,7 @@ def test_rowlines_kernel_move_by_move(es):
     long_row = 2 * (tj + u) + 1
     # (ei, ej, ek, gap, extra rows per plane, plane padding, source row padding, dst offset): whole tiles and ragged ones along i,
     # one to several windows beyond the minimum row length, several planes, rows whose phases differ from row to row
-    shapes = [(64, long_row, 3, 2, 2, 0, 0, 1), (128, long_row + 37, 2, 2, 0, 1, 0, 1), (70, 1026, 2, 4, 2, 0, 1, 5), (2, long_row + 5, 5, 1, 0, 3, 0, 0),
+    shapes = [(64, long_row, 3, 2, 2, 0, 0, 1), (128, long_row + 37, 2, 2, 0, 1, 0, 1), (70, 1026, 2, 4, 2, 0, 1, 5), (4, long_row + 5, 5, 1, 0, 3, 0, 0),
               (65, 513 + long_row, 1, 6, 0, 0, 2, 3), (200, long_row + 64, 4, 3, 1, 7, 0, 2), (33, 2050, 2, 2, 2, 0, 0, 2), (129, long_row + 130, 3, 8, 0, 5, 3, 7)]
     for ei, ej, ek, gap, xr, pp, spad, doff in shapes:
         if gap * 8 > ej:
@@ -325,7 +334,7 @@ def test_rowlines_kernel_random_sweep():
     from hypothesis import strategies as st
 
     @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
-    @given(es=st.sampled_from([4, 8, 16]), ei=st.integers(2, 200), ejq=st.integers(0, 500), ek=st.integers(1, 5),
+    @given(es=st.sampled_from([4, 8, 16]), ei=st.integers(4, 200), ejq=st.integers(0, 500), ek=st.integers(1, 5),
            gap=st.integers(1, 8), xr=st.integers(0, 3), pp=st.integers(0, 9), spad=st.integers(0, 3), doff=st.integers(0, 40),
            stream=st.booleans(), order=st.integers(0, 1), seed=st.integers(0, 1 << 20))
     def check(es, ei, ejq, ek, gap, xr, pp, spad, doff, stream, order, seed):
