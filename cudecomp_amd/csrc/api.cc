@@ -451,7 +451,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     h->tuning.no_streaming = envIsOne("CUDECOMP_DISABLE_STREAMING_ACCESS");
     // A transpose normally never touches the halo / padding cells of its OUTPUT pencil (reference transpose.h:830-895).  Two
     // kernels here read the few cells between consecutive output rows and write them back unchanged to write whole cache
-    // lines (rows_dense_kernel, transpose_lines_kernel): a caller who writes those cells on another stream WHILE the
+    // lines (rows_dense_kernel, transpose_lines_kernel, transpose_rowlines_kernel): a caller who writes those cells on another stream WHILE the
     // transpose runs opts out with this switch.
     if (envIsOne("CUDECOMP_PRESERVE_OUTPUT_HALOS")) h->tuning.dense_rows = 0;
     // Tuning switches (kernel variants, walk orders, diagnostic store policies): read by `make TUNING_VARIANTS=1` builds only

@@ -1,10 +1,12 @@
 // kernels.cc -- host side of the data-movement kernels: how a Move3D (plan.h) is executed on the GPU.
 //
 // A move is normalised (unit dims dropped, contiguous dims fused, dims sorted by source stride), classified -- row copy,
-// LDS-tiled transposition (plain or "window" for destinations off the 64-byte grid), generic element-wise -- and batched with its
+// LDS-tiled transposition (plain, "window" for destinations off the 64-byte grid, "lines" / "row lines" when whole rows of a
+// halo-carrying pencil are written), generic element-wise -- and batched with its
 // siblings (up to kMaxBatch moves, e.g. the per-peer pack copies of one transpose, share one launch; the descriptors travel in
 // the kernel argument segment).  The kernels themselves live in kernels_rows.hip, kernels_transpose.hip (one code object per
-// element size) and kernels_window.hip; kernels_dev.h says why they are separate code objects.
+// element size), kernels_window.hip, kernels_lines.hip, kernels_rowlines.hip and kernels_rotate.hip (the in-place rotation:
+// launched by the executor, transpose.cc); kernels_batch.h says why they are separate code objects.
 //
 // Pure data movement: no MFMA; the bound is HBM (8 TB/s spec, ~6.3 TB/s achievable copy rate).
 #include <algorithm>

@@ -27,7 +27,7 @@ struct KernelTuning {
   int walk_order = -1;           // transposes walk tiles i first (0) / j first (1); -1 = by strides (CUDECOMP_TILE_WALK)
   int interleave_rows = 1;       // batched row copies: workgroups serve the moves round robin (0: one move after the other)
   int dense_rows = -1;           // moves of whole rows onto halo-carrying pencils: 0 = never rewrite the halo / padding cells between
-                                 // consecutive rows (no rows_dense_kernel, no transpose_lines_kernel: the shifted / window kernels
+                                 // consecutive rows (no rows_dense_kernel, no transpose_lines_kernel / transpose_rowlines_kernel: the shifted / window kernels
                                  // instead); CUDECOMP_PRESERVE_OUTPUT_HALOS=1 in every build
   int lines_mode = -1;           // permutations onto halo-carrying pencils whose consecutive batch planes are adjacent rows:
                                  // -1 transpose_lines_kernel when it applies, 0 never (CUDECOMP_LINES_MODE, tuning builds)

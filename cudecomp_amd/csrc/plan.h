@@ -31,7 +31,7 @@ struct Move3D {
   // along the fastest memory axis) and this is the pencil's row pitch in elements.  The cells between the end of one row and
   // the start of the row one pitch further are then halo / padding cells of that pencil, written by nobody during the
   // operation, and the kernel layer may write whole cache lines across the row ends, putting back into those cells what it
-  // read from them (rows_dense_kernel, kernels_rows.hip; transpose_lines_kernel, kernels_lines.hip).  Only ever set for
+  // read from them (rows_dense_kernel, kernels_rows.hip; transpose_lines_kernel, kernels_lines.hip; transpose_rowlines_kernel, kernels_rowlines.hip).  Only ever set for
   // local destinations (never for puts into a peer's pencil).  THE RULE this rests on: during a transpose nobody writes the
   // halo / padding cells of its output pencil -- no move of the plan (checked over random decompositions, tests/test_plan_sim.py),
   // no one-sided write of a peer (direct puts address interior cells, halo plans never target a peer's pencil: they exchange
