@@ -1,6 +1,8 @@
 """(The verbatim case lists of the reference's runner are in tests/test_gpu_runner_cases.py; this file keeps a thinner,
 generator-based version of the same structure plus what the fixtures do not contain: 8-rank custom grids and the
-library's environment switches.)
+library's environment switches.  Since round 6 the generator-based DUPLICATES of the runner lists -- the first six test
+functions below -- are opt-in arms (CUDECOMP_TEST_EXTENDED=1; profiles/r06_gpu_suite_extended.log): the default run keeps
+the verbatim lists, the 8-rank grids and the switches.)
 
 The reference's own sweep structure (tests/test_config.yaml: transpose_test, _halo, _padding, _gdimdist, _mix, _ac,
 _rank_order and the halo_test family, with the skip rules of tests/test_runner.py:28-77) re-expressed as case files for
@@ -34,6 +36,7 @@ def _mem_orders():
     return ["--mem_order %s %s %s" % (x, y, x) for x, y in itertools.product(PERMS, PERMS)]
 
 
+@pytest.mark.extended
 @pytest.mark.parametrize("backends,shim", [([1, 2, 3, 6, 7, 8], False), ([4, 5], True)], ids=["one_sided", "rccl_path"])
 def test_sweep_transpose_base_all_memory_orders(backends, shim):
     if shim and not os.path.exists(SHIM):
@@ -46,6 +49,7 @@ def test_sweep_transpose_base_all_memory_orders(backends, shim):
     _run("transpose_test_R64", 4, lines, {"LD_PRELOAD": SHIM} if shim else None)
 
 
+@pytest.mark.extended
 @pytest.mark.parametrize("dtype", ["R32", "C32", "C64"])
 def test_sweep_transpose_base_other_dtypes(dtype):
     lines = [_tcase(pr, pc, b, extra=mo, oop=oop) for (pr, pc), b, mo, oop in
@@ -59,6 +63,7 @@ def _nonzero_pairs():
     return [(xz, y) for xz, y in itertools.product((Z, "1 1 1"), (Z, "1 1 1")) if (xz, y) != (Z, Z)]
 
 
+@pytest.mark.extended
 def test_sweep_transpose_halo_padding_gdimdist_mix():
     lines = []
     acs = ["--acx 0 --acy 0 --acz 0", "--acx 1 --acy 1 --acz 1"]
@@ -74,6 +79,7 @@ def test_sweep_transpose_halo_padding_gdimdist_mix():
     _run("transpose_test_R32", 4, lines)
 
 
+@pytest.mark.extended
 def test_sweep_transpose_ac_and_rank_order():
     lines = [_tcase(pr, pc, 1, extra="--acx %d --acy %d --acz %d" % ac, oop=oop) for (pr, pc), ac, oop in
              itertools.product(PDIMS, itertools.product((0, 1), repeat=3), (True, False))]
@@ -87,6 +93,7 @@ def _hcase(pr, pc, backend, ax, gd=Z, h=(1, 1, 1), per=(1, 1, 1), pad=(0, 0, 0),
                                                                 (ax, extra))).strip()
 
 
+@pytest.mark.extended
 @pytest.mark.parametrize("backends,shim", [([1, 2, 4, 5], False), ([3], True)], ids=["one_sided", "rccl_path"])
 @pytest.mark.parametrize("dtype", ["R64", "C32"])
 def test_sweep_halo_base_all_memory_orders(backends, shim, dtype):
@@ -108,6 +115,7 @@ def _halo_period_combos():
     return out
 
 
+@pytest.mark.extended
 def test_sweep_halo_mix_padding_gdimdist_ac_rank_order():
     lines = []
     pads = [p for p in itertools.product((0, 1), repeat=3) if p != (0, 0, 0)]
