@@ -477,6 +477,7 @@ cudecompResult_t cudecompInit(cudecompHandle_t* handle_out, MPI_Comm mpi_comm) {
     tuningSwitch("CUDECOMP_LINES_RUN_KIB", &h->tuning.lines_run_kib);
     tuningSwitch("CUDECOMP_LINES_WALK", &h->tuning.lines_walk);
     tuningSwitch("CUDECOMP_LINES_GROUP", &h->tuning.lines_group);
+    tuningSwitch("CUDECOMP_ROTATE_WALK", &h->tuning.rotate_walk);
     if (const char* v = std::getenv("CUDECOMP_FORCE_GENERIC_KERNELS"))
       if (std::strtol(v, nullptr, 10) == 1) h->tuning.force_class = MOVE_GENERIC;
 

@@ -36,6 +36,7 @@ struct KernelTuning {
   int lines_group = 16;          // its tile walk: tile rows per group, 0 = all (CUDECOMP_LINES_GROUP)
   int lines_run_kib = -1;        // ... and KiB of every destination slab written before the next tile row of the group; 0 = one
                                  // window (tile rows first inside the group), -1 = by shape (CUDECOMP_LINES_RUN_KIB)
+  int rotate_walk = -1;          // in-place rotation: the orbit walk, -1 = default (kernels_rotate.hip; CUDECOMP_ROTATE_WALK)
   int window_mode = -1;          // transposes onto rows off the 64-byte grid: -1 window kernel for moves >= 1 MiB, 0 never, 1 always
   int window_wide = 0;           // window kernel, 8-byte elements: 1 = 128 x 64 tiles with 512 threads (CUDECOMP_WINDOW_WIDE=1)
   int tile_shape = -1;           // 4-byte transposes with 16-byte lanes: 64 x 128 tiles (2, the default), 64 x 64 (0) or 128 x 64 (1);

@@ -62,6 +62,6 @@ int linesUnitBytes(int unit_choice);  // the unit the build really has for a wis
 void launchRowLinesBatch(int es, int variant, int stream_access, const kern::Batch& b, unsigned int blocks, hipStream_t stream);
 // kernels_rotate.hip: in-place rotation of a cubic n^3 array (direction +1: new[p0,p1,p2] = old[p2,p0,p1]; -1: the inverse)
 bool rotateSupported(int es, long long n);
-void launchRotate(void* buffer, long long n, int es, int direction, hipStream_t stream);
+void launchRotate(void* buffer, long long n, int es, int direction, hipStream_t stream, int walk = -1);
 
 }  // namespace cudecomp

@@ -242,7 +242,7 @@ void executeTranspose(cudecompHandle_t h, cudecompGridDesc_t gd, const Transpose
     gd->path_count[PATH_LOCAL]++;
     if (plan.rotate && input == output && h->inplace_rotation && rotateSupported(es, plan.rotate_n)) {
       // in place on a cubic 1 x 1 grid: one rotation kernel, one read and one write per element (kernels_rotate.hip)
-      launchRotate(input, plan.rotate_n, es, plan.rotate, stream);
+      launchRotate(input, plan.rotate_n, es, plan.rotate, stream, h->tuning.rotate_walk);
       gd->rotations++;
       perfMark(pev, 1, stream);
       perfMark(pev, 2, stream);

@@ -146,7 +146,7 @@ def test_in_place_rotation_of_cubic_grids(kind):
     reference stages such transposes through the workspace, include/internal/transpose.h:326-362).  Against the oracle after
     every hop; cubes the tiles divide run it (counted), others and CUDECOMP_DISABLE_INPLACE_ROTATION keep the staged form."""
     tile = 8 if kind == 3 else 16
-    for n in (tile, 2 * tile, 3 * tile, 5 * tile):
+    for n in (tile, 2 * tile, 3 * tile, 5 * tile, 9 * tile):   # (walk cubes of 1, 2, 2, 4 and 8 blocks per edge, whole and ragged)
         args = {"gdims": (n, n, n), "pdims": (1, 1), "ac": K.ALL_AC, "kind": kind, "out_of_place": [False], "expect_path": ["rotations"]}
         assert B.transpose_chain(0, 1, args) == []
     # a cube the tiles do not divide, a non-cubic grid, fp32: staged, same results
