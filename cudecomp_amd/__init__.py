@@ -143,7 +143,7 @@ EXT_SYMBOLS = ["cudecompExtGetTransposePlan", "cudecompExtGetHaloPlan", "cudecom
                "cudecompExtPlanTranspose", "cudecompExtPlanHalo", "cudecompExtPencilInfo", "cudecompExtShiftedRank",
                "cudecompExtWorkspaceSizes", "cudecompExtGetLinkInfo", "cudecompExtLastKernelName",
                "cudecompExtRunLocalPhases", "cudecompExtEstimateCycleMs", "cudecompExtTrimWorkspacePool", "cudecompExtPlanRelay", "cudecompExtQueueCensus",
-               "cudecompExtDescribeMove"]
+               "cudecompExtDescribeMove", "cudecompExtRotateWalk"]
 
 
 class ExtTransposeTimings(C.Structure):
@@ -230,6 +230,7 @@ def lib():
         L.cudecompExtMove3D.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32, pi32, vp]
         L.cudecompExtDescribeMove.argtypes = [C.c_uint64, C.c_uint64, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), i32,
                                               C.POINTER(i64)]
+        L.cudecompExtRotateWalk.argtypes = [i32, i32, i64, i64, pi32, C.POINTER(i64)]
         _lib = L
     return _lib
 
@@ -503,6 +504,18 @@ def cudecompExtMove3D(src, dst, es, extent, ss, ds, force_generic=False, stream=
     _check(lib().cudecompExtMove3D(src, dst, es, a(extent), a(ss), a(ds), int(force_generic), C.byref(cls), stream),
            "cudecompExtMove3D")
     return cls.value
+
+
+def cudecompExtRotateWalk(nb, walk=-1):
+    """The in-place rotation kernel's orbit walk for nb blocks per edge (no launch, no GPU): (grid, blocks) with blocks an
+    int32 array of shape (grid, 3): the block triple of every workgroup, -1 -1 -1 for the ones that map to none."""
+    import numpy as np
+    grid = C.c_int64()
+    _check(lib().cudecompExtRotateWalk(nb, walk, 0, 0, None, C.byref(grid)), "cudecompExtRotateWalk")
+    blocks = np.empty((grid.value, 3), dtype=np.int32)
+    _check(lib().cudecompExtRotateWalk(nb, walk, 0, grid.value, blocks.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(grid)),
+           "cudecompExtRotateWalk")
+    return grid.value, blocks
 
 
 def cudecompExtDescribeMove(src_address, dst_address, es, extent, ss, ds, flags=0, row_pitch=0):

@@ -7,6 +7,7 @@
 #include "cudecomp_ext.h"
 #include "errors.h"
 #include "internal.h"
+#include "rotate_walk.h"
 #include "transport.h"
 
 using namespace cudecomp;
@@ -513,6 +514,25 @@ cudecompResult_t cudecompExtRunLocalPhases(const cudecompExtGridSpec_t* grid, in
     };
     if (phases & 1) run(p.pack);
     if (phases & 2) run(p.unpack);
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (...) {
+    return CUDECOMP_RESULT_INTERNAL_ERROR;
+  }
+  return CUDECOMP_RESULT_SUCCESS;
+}
+
+cudecompResult_t cudecompExtRotateWalk(int32_t nb, int32_t walk, int64_t first, int64_t count, int32_t* blocks, int64_t* grid) {
+  try {
+    if (nb < 1 || nb > 1024 || !grid || first < 0 || count < 0 || (count > 0 && !blocks)) CD_INVALID_USAGE("bad argument");
+    const int w = rotateWalkFor(walk, nb);
+    *grid = rotateWalkGrid(nb, w);
+    if (first + count > *grid) CD_INVALID_USAGE("workgroups beyond the grid");
+    for (int64_t i = 0; i < count; ++i) {
+      int b0 = -1, b1 = -1, b2 = -1;
+      if (!rotateWalkBlock((unsigned int)(first + i), (unsigned int)nb, w, &b0, &b1, &b2)) b0 = b1 = b2 = -1;
+      blocks[3 * i] = b0, blocks[3 * i + 1] = b1, blocks[3 * i + 2] = b2;
+    }
   } catch (const Error& e) {
     return fail(e);
   } catch (...) {

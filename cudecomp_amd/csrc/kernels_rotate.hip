@@ -7,6 +7,7 @@
 #include "kernels_dev.h"
 
 #include "errors.h"
+#include "rotate_walk.h"
 
 namespace cudecomp {
 namespace kern {
@@ -32,7 +33,7 @@ namespace {
 // Granularity: a tile row is T elements = 128 bytes for 8-byte elements (one cache line), which is what the cubic tiles of an
 // in-place rotation allow (a tile that is longer along p0 has an image that is longer along p1: no closed set of boxes).
 template <int ES, int T, bool FWD>
-__global__ __launch_bounds__(kThreads) void rotate_kernel(char* base, int n, int nb, int cl, unsigned int shear) {
+__global__ __launch_bounds__(kThreads) void rotate_kernel(char* base, int n, int nb, int walk) {
   using E = Bytes<ES>;
   constexpr int VW = 16 / ES;               // elements per 16-byte vector
   using V = Bytes<ES * VW>;
@@ -42,31 +43,9 @@ __global__ __launch_bounds__(kThreads) void rotate_kernel(char* base, int n, int
   static_assert(TILE % (kThreads * VW) == 0 && T % VW == 0, "rotate mapping");
   __shared__ __attribute__((aligned(16))) E tile[T * PY];
 
-  // Walk (which orbit a workgroup takes).  The three tiles of an orbit have the p0 blocks b0, b2 and b1, i.e. those are their
-  // address bits 7 and up -- the bits that choose the L2 channel inside an XCD and the HBM channel behind it.  Workgroup w runs on
-  // XCD w % 8 (round-robin dispatch), so with b0 = w % nb an XCD would see 1/8 of the b0 values and ONE value of b1 and b2 for
-  // thousands of workgroups: measured 0.56 of the HBM peak at 1024^3 fp64, 0.50 for complex128.  The default walk (cl == 15)
-  // numbers the workgroups OF AN XCD, s = w / 8: b0 = s % nb runs through all blocks on every XCD, (b1, b2) come from the rest
-  // and the XCD, and two shears b1 += a * b0, b2 += b * b0 + c * b1 (bijections of the triples) make b1 and b2 run with it:
-  // 0.64 / 0.63 (profiles/r06_tuning.md section 8; 64 shears within +-1 %, cubes of 2^cl blocks per edge, cl = 0..5, behind).
-  const unsigned int wg = blockIdx.x;
+  // which orbit this workgroup takes: rotate_walk.h
   int b0, b1, b2;
-  if (cl == 15) {
-    const unsigned int x = wg & 7u, s = wg >> 3, u = s % (unsigned int)nb, m = (s / (unsigned int)nb) * 8u + x;
-    if (m >= (unsigned int)nb * (unsigned int)nb) return;
-    b0 = (int)u, b1 = (int)(m % (unsigned int)nb), b2 = (int)(m / (unsigned int)nb);
-  } else {  // (tuning builds: CUDECOMP_ROTATE_WALK) b0 fastest inside cubes of 2^cl blocks per edge, cubes c0 fastest
-    const unsigned int cm = (1u << cl) - 1u;
-    const unsigned int within = wg & ((1u << (3 * cl)) - 1u), cube = wg >> (3 * cl);
-    const unsigned int nc = ((unsigned int)nb + cm) >> cl;
-    b0 = (int)(((cube % nc) << cl) + (within & cm));
-    b1 = (int)((((cube / nc) % nc) << cl) + ((within >> cl) & cm));
-    b2 = (int)(((cube / (nc * nc)) << cl) + (within >> (2 * cl)));
-    if (b0 >= nb || b1 >= nb || b2 >= nb) return;
-  }
-  // shears: shear = a | b << 4 | c << 8
-  b2 = (int)(((unsigned int)b2 + ((shear >> 4) & 15u) * (unsigned int)b0 + ((shear >> 8) & 15u) * (unsigned int)b1) % (unsigned int)nb);
-  b1 = (int)(((unsigned int)b1 + (shear & 15u) * (unsigned int)b0) % (unsigned int)nb);
+  if (!rotateWalkBlock(blockIdx.x, (unsigned int)nb, walk, &b0, &b1, &b2)) return;
   // owner of the orbit {(b0,b1,b2), (b2,b0,b1), (b1,b2,b0)}: the lexicographically smallest triple (b2 most significant)
   const long long key0 = ((long long)b2 * nb + b1) * nb + b0, key1 = ((long long)b1 * nb + b0) * nb + b2, key2 = ((long long)b0 * nb + b2) * nb + b1;
   if (key0 > key1 || key0 > key2) return;
@@ -159,41 +138,26 @@ __global__ __launch_bounds__(kThreads) void rotate_kernel(char* base, int n, int
 // 64-byte rows (half lines) and keep the staged form
 static int rotateTile(int es) { return es == 8 ? 16 : (es == 16 ? 8 : 0); }
 
-// the walk: cl | a << 4 | b << 8 | c << 12 (see the kernel); cl = 15 the per-XCD walk, 0..5 cubes of 2^cl blocks per edge
-constexpr int kRotateWalk = 15 | 1 << 4 | 3 << 8 | 2 << 12;
-
-static long long rotateGrid(long long nb, int cl) {
-  if (cl == 15) return 8 * nb * ((nb * nb + 7) / 8);
-  const long long nc = (nb + (1ll << cl) - 1) >> cl;
-  return nc * nc * nc << (3 * cl);
-}
-
 bool rotateSupported(int es, long long n) {
   const int t = rotateTile(es);
   // (the grid bound holds for every walk: at most 2^5 - 1 blocks of padding per axis)
-  return t > 0 && n >= t && n % t == 0 && rotateGrid(n / t + 31, 0) < 0x7fffffffLL && n * n * n < (1ll << 40);
+  return t > 0 && n >= t && n % t == 0 && rotateWalkGrid(n / t + 31, 0) < 0x7fffffffLL && n * n * n < (1ll << 40);
 }
 
 // direction: +1 forward (new[p0,p1,p2] = old[p2,p0,p1]), -1 inverse; buffer = the N^3 array (in place)
-// walk: -1 = default, else as kRotateWalk (CUDECOMP_ROTATE_WALK in tuning builds)
+// walk: -1 = default, else as rotate_walk.h says (CUDECOMP_ROTATE_WALK in tuning builds)
 void launchRotate(void* buffer, long long n, int es, int direction, hipStream_t stream, int walk) {
   if (!rotateSupported(es, n)) CD_INTERNAL_ERROR("in-place rotation not available for this shape");
   const int nb = (int)(n / rotateTile(es));
-  if (walk < 0) walk = kRotateWalk;
-  int cl = walk & 15;
-  if (cl != 15) {
-    if (cl > 5) cl = 5;
-    while (cl > 0 && (1 << cl) > nb) --cl;
-  }
-  const unsigned int shear = (unsigned int)walk >> 4 & 0xfffu;
-  const dim3 grid((unsigned int)rotateGrid(nb, cl)), block(kern::kThreads);
+  walk = rotateWalkFor(walk, nb);
+  const dim3 grid((unsigned int)rotateWalkGrid(nb, walk)), block(kern::kThreads);
   char* b = static_cast<char*>(buffer);
   if (es == 8) {
-    if (direction > 0) kern::rotate_kernel<8, 16, true><<<grid, block, 0, stream>>>(b, (int)n, nb, cl, shear);
-    else kern::rotate_kernel<8, 16, false><<<grid, block, 0, stream>>>(b, (int)n, nb, cl, shear);
+    if (direction > 0) kern::rotate_kernel<8, 16, true><<<grid, block, 0, stream>>>(b, (int)n, nb, walk);
+    else kern::rotate_kernel<8, 16, false><<<grid, block, 0, stream>>>(b, (int)n, nb, walk);
   } else {
-    if (direction > 0) kern::rotate_kernel<16, 8, true><<<grid, block, 0, stream>>>(b, (int)n, nb, cl, shear);
-    else kern::rotate_kernel<16, 8, false><<<grid, block, 0, stream>>>(b, (int)n, nb, cl, shear);
+    if (direction > 0) kern::rotate_kernel<16, 8, true><<<grid, block, 0, stream>>>(b, (int)n, nb, walk);
+    else kern::rotate_kernel<16, 8, false><<<grid, block, 0, stream>>>(b, (int)n, nb, walk);
   }
   CD_CHECK_HIP(hipGetLastError());
 }

@@ -236,6 +236,12 @@ cudecompResult_t cudecompExtMove3D(const void* src, void* dst, int32_t es, const
 cudecompResult_t cudecompExtDescribeMove(uint64_t src_address, uint64_t dst_address, int32_t es, const int64_t extent[3],
                                         const int64_t ss[3], const int64_t ds[3], int32_t flags, int64_t out[10]);
 
+/* The orbit walk of the in-place rotation kernel (csrc/rotate_walk.h; no launch, works without a GPU): for an array of nb
+ * blocks per edge and walk (-1 = the default), *grid = the workgroups a launch has, and for workgroups first .. first + count - 1
+ * blocks[3 * i .. 3 * i + 2] = the block triple (b0, b1, b2) of workgroup first + i, or -1 -1 -1 when it maps to none (padding).
+ * blocks may be NULL (count 0).  Harness-only (tests/test_kernel_plan.py: every walk visits every triple exactly once). */
+cudecompResult_t cudecompExtRotateWalk(int32_t nb, int32_t walk, int64_t first, int64_t count, int32_t* blocks, int64_t* grid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -365,6 +365,35 @@ def test_rotation_restatement_closes_every_orbit():
             assert new.reshape(-1)[y + n * (z + n * x)] == a[x + n * (y + n * z)]
 
 
+def test_rotation_walks_visit_every_block_triple_once():
+    """The orbit walk of rotate_kernel (csrc/rotate_walk.h, the code the kernel runs, through cudecompExtRotateWalk): for every array
+    size and walk -- the default per-XCD walk with its shears, the cube walks of tuning builds, more shears -- every block triple
+    is taken by exactly one workgroup, the rest of the grid maps to none, and the padding stays small.  On the default walk every
+    XCD (workgroup % 8) steps through ALL p0 blocks of all three tiles of its orbits within any nb consecutive workgroups of
+    its own: what the walk is for (profiles/r06_tuning.md section 8)."""
+    default = 15 | 1 << 4 | 3 << 8 | 2 << 12
+    walks = [-1, default, 15, 0, 1, 2, 3, 5, 1 | 2 << 4 | 3 << 8 | 3 << 12, 15 | 15 << 4 | 15 << 8 | 15 << 12, 2 | 7 << 8]
+    for nb in (1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 24, 33, 64):
+        for walk in walks:
+            grid, blocks = cd.cudecompExtRotateWalk(nb, walk)
+            assert blocks.shape == (grid, 3)
+            valid = blocks[blocks[:, 0] >= 0]
+            assert ((blocks >= 0).all(axis=1) | (blocks == -1).all(axis=1)).all()
+            assert len(valid) == nb ** 3 and (valid < nb).all(), (nb, walk)
+            keys = (valid[:, 2].astype(np.int64) * nb + valid[:, 1]) * nb + valid[:, 0]
+            assert len(np.unique(keys)) == nb ** 3, (nb, walk)
+            assert grid <= (nb + 31) ** 3 and (walk not in (-1, default) or grid <= nb ** 3 + 8 * nb), (nb, walk, grid)
+    for nb in (16, 64):
+        grid, blocks = cd.cudecompExtRotateWalk(nb)
+        assert grid == nb ** 3
+        for x in range(8):
+            mine = blocks[x::8]
+            for start in (0, nb, 5 * nb, len(mine) - nb):   # (windows of one value of s // nb)
+                window = mine[start:start + nb]
+                for col in range(3):   # p0 blocks of the three tiles of an orbit: b0, b2, b1
+                    assert len(np.unique(window[:, col])) == nb, (nb, x, start, col)
+
+
 # ---- permutations onto halo-carrying pencils whose adjacent rows are the tile's OWN rows: transpose_rowlines_kernel -------------
 ROWLINES = 16  # walk bit
 
