@@ -110,6 +110,10 @@ inline int envRankOr(const char* const* names, int dflt) {
     if (const char* v = std::getenv(names[i])) return std::atoi(v);
   return dflt;
 }
+inline int envIntOr(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : dflt;
+}
 #ifdef NATIVE_WITH_MPI
 inline int worldRank() {
   int r = 0;
@@ -204,7 +208,8 @@ inline int reduceVerdict(int mine, int case_index) {
   }
   if (rank != 0) return mine;
   int worst = mine;
-  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300);
+  // (how long rank 0 waits for a rank that has died without a verdict: CUDECOMP_TEST_VERDICT_TIMEOUT seconds, default 300)
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(envIntOr("CUDECOMP_TEST_VERDICT_TIMEOUT", 300));
   for (int r = 0; r < n; ++r) {
     for (;;) {
       std::ifstream f(name(r));
@@ -601,6 +606,7 @@ int nativeMain(int argc, char** argv, RunCase run_case) {
   auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   if (from_file && rank == 0) printf("Running %d tests...\n", (int)cases.size());
   int any_local_failure = 0;
+  const bool stop_at_first_failure = envIntOr("CUDECOMP_TEST_STOP_AT_FIRST_FAILURE", 0) != 0;
   for (size_t i = 0; i < cases.size(); ++i) {
     if (from_file && rank == 0) printf("command: %s %s\n", argv[0], cases[i].c_str());
     int res = 1;
@@ -611,6 +617,7 @@ int nativeMain(int argc, char** argv, RunCase run_case) {
     }
     any_local_failure |= res;
     if (rank == 0 && (res || i == cases.size() / 2)) noteQueues(handle);  // at failures, and once while everybody is busy
+    const int mine = res;
     res = reduceVerdict(res, (int)i);
     if (rank == 0) {
       if (from_file) printf(res ? " FAILED\n" : " PASSED\n");
@@ -618,6 +625,14 @@ int nativeMain(int argc, char** argv, RunCase run_case) {
       if (from_file && (i + 1) % 10 == 0)
         printf("Completed %d/%d tests, running time %f s\n", (int)i + 1, (int)cases.size(), elapsed());
       fflush(stdout);
+    }
+    // CUDECOMP_TEST_STOP_AT_FIRST_FAILURE=1 (the pytest harness): a rank leaves the list at the first case that failed for it
+    // (rank 0: for anybody).  After a failed case the ranks are no longer in step -- a rank that threw skipped collectives the others
+    // entered -- so the cases that follow fail for that reason and, with peers gone, only after time-outs.  The reference's
+    // protocol (run everything, list the failing cases) stays the default.
+    if (stop_at_first_failure && (mine || (rank == 0 && res))) {
+      if (rank == 0) printf("Stopping at the first failing case (%d of %d run).\n", (int)i + 1, (int)cases.size());
+      break;
     }
   }
   InputGate::get().report();

@@ -35,15 +35,25 @@ def _check_logs(binary, lines, logs):
     assert ok, out[-3000:]
 
 
+# The one platform error these programs get a second attempt for: the runtime refuses to EXPORT a fresh device allocation over IPC
+# ("hipIpcGetMemHandle failed: invalid argument", on the importing ranks "a peer rank could not export its buffer over IPC").  Seen
+# twice in about twenty suite runs of round 6, both times with eight processes on the one GPU creating and releasing shared
+# workspaces (gpurun_out/r06_sixth: subcomm_test; profiles/r06_ipc_export_refused.log: the CUDECOMP_WORKSPACE_POOL_MIB=0 arm of the
+# switch sweep); the library had already tried four allocations at other addresses (csrc/transport.cc workspaceAllocRaw) and goes on
+# without the one-sided transport, which the backends of these lists need.  Not a property of the kernels or plans under test.
+_IPC_EXPORT_REFUSED = ("could not export its buffer over IPC", "hipIpcGetMemHandle failed")
+
+
 def _run(binary, nranks, lines, env=None):
     """Runs the case list through the native test program (reference protocol: every case PASSED, "Passed all tests.").
-    Every failure is a failure: nothing is repeated."""
+    Every failure is a failure; the only repetition is the one _IPC_EXPORT_REFUSED describes."""
     _run_side_by_side([(binary, nranks, lines, env)])
 
 
 def _run_side_by_side(jobs, path_of=None):
     """jobs = [(binary, nranks, lines, env)]: independent case lists, launched together while they fit on the GPU side by side
-    (tests/mp.py: run_binary_groups); every list is checked like _run's."""
+    (tests/mp.py: run_binary_groups); every list is checked like _run's.  The programs stop at their first failing case
+    (CUDECOMP_TEST_STOP_AT_FIRST_FAILURE, tests/native/native_test.h): what follows a failure is ranks out of step, not evidence."""
     from tests.mp import run_binary_groups
     paths, groups = [], []
     for binary, nranks, lines, env in jobs:
@@ -51,13 +61,25 @@ def _run_side_by_side(jobs, path_of=None):
             f.write("\n".join(lines) + "\n")
             paths.append(f.name)
         exe = path_of(binary) if path_of else _binary(binary)
+        env = dict(env or {})
+        env.setdefault("CUDECOMP_TEST_STOP_AT_FIRST_FAILURE", "1")
+        env.setdefault("CUDECOMP_TEST_VERDICT_TIMEOUT", "60")
         groups.append((nranks, [exe, "--testfile", paths[-1]], 900, env))
     try:
-        all_logs = run_binary_groups(groups)
+        all_logs = run_binary_groups(groups, collect_errors=True)
+        for i, ((binary, nranks, lines, env), logs) in enumerate(zip(jobs, all_logs)):
+            text = str(logs) if isinstance(logs, AssertionError) else "\n".join(logs)
+            passed = not isinstance(logs, AssertionError) and " FAILED" not in logs[0] and "Passed all tests." in logs[0]
+            if not passed and any(sig in text for sig in _IPC_EXPORT_REFUSED):
+                print("%s (%d ranks): the runtime refused to export a fresh workspace over IPC (platform hiccup, see "
+                      "_IPC_EXPORT_REFUSED); one more attempt of this list, alone" % (binary, nranks))
+                all_logs[i] = run_binary_groups([groups[i]], collect_errors=True)[0]
     finally:
         for p in paths:
             os.unlink(p)
     for (binary, nranks, lines, env), logs in zip(jobs, all_logs):
+        if isinstance(logs, AssertionError):
+            raise logs
         _check_logs(binary, lines, logs)
 
 
@@ -82,6 +104,26 @@ def test_native_transpose_single_rank(dtype):
         lines += ["--pr 1 --pc 1 --gx 20 --gy 18 --gz 22 --backend 4 --mem_order %s %s %s %s" % (x, y, x, o)
                   for x, y in itertools.product(perms, perms) for o in ("", "-o")]
     _run("transpose_test_" + dtype, 1, lines)
+
+
+def test_native_list_stops_at_its_first_failing_case():
+    """CUDECOMP_TEST_STOP_AT_FIRST_FAILURE=1 (what _run_side_by_side sets): the second of four cases asks for a 3 x 1 grid on two
+    ranks -- refused by cudecompGridDescCreate on every rank -- and the program ends there, failing, within seconds."""
+    import time
+    good = _transpose_lines([(2, 1)], [1], full=False)[:3]
+    lines = [good[0], good[1].replace("--pr 2", "--pr 3"), good[1], good[2]]
+    with tempfile.NamedTemporaryFile("w", suffix="_cases.txt", delete=False) as f:
+        f.write("\n".join(lines) + "\n")
+    t0 = time.time()
+    try:
+        with pytest.raises(AssertionError) as e:
+            run_binary_ranks(2, [_binary("transpose_test_R64"), "--testfile", f.name], 120,
+                             {"CUDECOMP_TEST_STOP_AT_FIRST_FAILURE": "1", "CUDECOMP_TEST_VERDICT_TIMEOUT": "60"})
+    finally:
+        os.unlink(f.name)
+    text = str(e.value)
+    assert "Stopping at the first failing case (2 of 4 run)" in text and text.count(" PASSED") == 1, text[-2000:]
+    assert time.time() - t0 < 60
 
 
 @pytest.mark.parametrize("dtype", ["R64", "C32"])

@@ -70,3 +70,39 @@ def test_fresh_processes_on_request_and_for_the_bodies_about_process_state():
         assert {r["pid"] for r in c}.isdisjoint({r["pid"] for r in d})
     finally:
         del os.environ[mp.POOL_SWITCH]
+
+
+def test_native_lists_get_one_more_attempt_for_a_refused_ipc_export_only(monkeypatch, capsys):
+    """tests/test_gpu_native.py::_run_side_by_side: a list whose failure carries the signature of the runtime refusing to export a
+    fresh workspace over IPC is run once more, alone, and says so; any other failure is raised as it is; nothing is repeated twice."""
+    from tests import test_gpu_native as N
+    good = ["command: x\n PASSED\nPassed all tests.\n"]
+    calls = []
+
+    def fake_groups(script):
+        def run(groups, max_ranks=8, collect_errors=False):
+            assert collect_errors
+            calls.append([(g[0], dict(g[3])) for g in groups])
+            return [script.pop(0) for _ in groups]
+        return run
+
+    monkeypatch.setattr(N, "_binary", lambda name: "/bin/true")
+    refused = AssertionError("rank 0 exit 1\nCUDECOMP:ERROR: ... (a peer rank could not export its buffer over IPC)\n FAILED")
+    # two lists side by side, the second one hits the platform error: only that one runs again, alone, and passes
+    monkeypatch.setattr(mp, "run_binary_groups", fake_groups([good, refused, good]))
+    N._run_side_by_side([("transpose_test_R64", 4, ["a"], None), ("halo_test_R64", 4, ["b"], {"X": "1"})])
+    assert [len(c) for c in calls] == [2, 1] and calls[1][0][1]["X"] == "1"
+    assert all(env["CUDECOMP_TEST_STOP_AT_FIRST_FAILURE"] == "1" for c in calls for _, env in c)
+    assert "one more attempt" in capsys.readouterr().out
+    # the second attempt fails as well: raised
+    del calls[:]
+    monkeypatch.setattr(mp, "run_binary_groups", fake_groups([refused, refused]))
+    with pytest.raises(AssertionError, match="could not export"):
+        N._run_side_by_side([("transpose_test_R64", 4, ["a"], None)])
+    assert len(calls) == 2
+    # another failure (a wrong cell): no second attempt
+    del calls[:]
+    monkeypatch.setattr(mp, "run_binary_groups", fake_groups([["command: x\n FAILED\nFailed 1/1 tests.\n"]]))
+    with pytest.raises(AssertionError):
+        N._run_side_by_side([("transpose_test_R64", 4, ["a"], None)])
+    assert len(calls) == 1
