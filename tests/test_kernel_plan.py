@@ -385,7 +385,7 @@ def test_rotation_walks_visit_every_block_triple_once():
             assert grid <= (nb + 31) ** 3 and (walk not in (-1, default) or grid <= nb ** 3 + 8 * nb), (nb, walk, grid)
     for nb in (16, 64):
         grid, blocks = cd.cudecompExtRotateWalk(nb)
-        assert grid == nb ** 3
+        assert grid == nb ** 3 and np.array_equal(blocks, cd.cudecompExtRotateWalk(nb, default)[1])   # (the pinned default)
         for x in range(8):
             mine = blocks[x::8]
             for start in (0, nb, 5 * nb, len(mine) - nb):   # (windows of one value of s // nb)
