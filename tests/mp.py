@@ -316,7 +316,36 @@ def _pool_run(nranks, module, func, args, timeout, extra_env):
         raise
 
 
+# The one platform error a launch gets a second attempt for: the runtime refuses to EXPORT a fresh device allocation over IPC
+# ("hipIpcGetMemHandle failed: invalid argument"; on the importing ranks "a peer rank could not export its buffer over IPC").  Seen
+# twice in about twenty suite runs of round 6, both times with eight processes on the one GPU creating and releasing shared workspaces
+# (gpurun_out/r06_sixth: subcomm_test; profiles/r06_ipc_export_refused.log: the CUDECOMP_WORKSPACE_POOL_MIB=0 arm of the switch sweep);
+# the library had already tried four allocations at other addresses (csrc/transport.cc workspaceAllocRaw) and goes on without the
+# one-sided transport, which the backends under test need.  Not a property of the kernels, plans or transports.
+IPC_EXPORT_REFUSED = ("could not export its buffer over IPC", "hipIpcGetMemHandle failed")
+
+
+def _second_attempt_if_export_refused(what, launch):
+    try:
+        return launch()
+    except AssertionError as e:
+        if not any(sig in str(e) for sig in IPC_EXPORT_REFUSED):
+            raise
+        print("%s: the runtime refused to export a fresh workspace over IPC (platform hiccup, tests/mp.py IPC_EXPORT_REFUSED); "
+              "one more attempt, in new processes" % what)
+        pool_stop(kill=True)
+        pool_stats["second_attempts"] = pool_stats.get("second_attempts", 0) + 1
+        return launch()
+
+
 def run_ranks(nranks, module, func, args=None, timeout=300, extra_env=None, per_rank_env=None, fresh=None):
+    """`func(rank, nranks, args)` of `module` on N ranks (the rank pool, or fresh processes); returns the per-rank results, raises
+    AssertionError with the ranks' output on any failure.  The only repetition: _second_attempt_if_export_refused."""
+    return _second_attempt_if_export_refused("%s.%s on %d ranks" % (module, func, nranks), lambda: _run_ranks_once(
+        nranks, module, func, args, timeout, extra_env, per_rank_env, fresh))
+
+
+def _run_ranks_once(nranks, module, func, args=None, timeout=300, extra_env=None, per_rank_env=None, fresh=None):
     if fresh is None:
         fresh = (os.environ.get(POOL_SWITCH, "1") == "0" or module != "tests.gpu_bodies" or func in FRESH_FUNCS or
                  per_rank_env is not None or nranks > 8)
@@ -457,7 +486,13 @@ if __name__ == "__main__":
 
 def run_binary_ranks(nranks, argv, timeout=300, extra_env=None):
     """Launch a native executable (C / Fortran test twin) on N ranks with the same launcher environment;
-    returns the list of per-rank stdout+stderr texts, raising on any non-zero exit."""
+    returns the list of per-rank stdout+stderr texts, raising on any non-zero exit.  The only repetition:
+    _second_attempt_if_export_refused."""
+    return _second_attempt_if_export_refused("%s on %d ranks" % (os.path.basename(str(argv[0])), nranks),
+                                             lambda: _run_binary_ranks_once(nranks, argv, timeout, extra_env))
+
+
+def _run_binary_ranks_once(nranks, argv, timeout=300, extra_env=None):
     import uuid
     pool_stop()
     port_a, port_b = free_port(), free_port()

@@ -35,18 +35,9 @@ def _check_logs(binary, lines, logs):
     assert ok, out[-3000:]
 
 
-# The one platform error these programs get a second attempt for: the runtime refuses to EXPORT a fresh device allocation over IPC
-# ("hipIpcGetMemHandle failed: invalid argument", on the importing ranks "a peer rank could not export its buffer over IPC").  Seen
-# twice in about twenty suite runs of round 6, both times with eight processes on the one GPU creating and releasing shared
-# workspaces (gpurun_out/r06_sixth: subcomm_test; profiles/r06_ipc_export_refused.log: the CUDECOMP_WORKSPACE_POOL_MIB=0 arm of the
-# switch sweep); the library had already tried four allocations at other addresses (csrc/transport.cc workspaceAllocRaw) and goes on
-# without the one-sided transport, which the backends of these lists need.  Not a property of the kernels or plans under test.
-_IPC_EXPORT_REFUSED = ("could not export its buffer over IPC", "hipIpcGetMemHandle failed")
-
-
 def _run(binary, nranks, lines, env=None):
     """Runs the case list through the native test program (reference protocol: every case PASSED, "Passed all tests.").
-    Every failure is a failure; the only repetition is the one _IPC_EXPORT_REFUSED describes."""
+    Every failure is a failure; the only repetition is the one tests/mp.py IPC_EXPORT_REFUSED describes."""
     _run_side_by_side([(binary, nranks, lines, env)])
 
 
@@ -66,20 +57,11 @@ def _run_side_by_side(jobs, path_of=None):
         env.setdefault("CUDECOMP_TEST_VERDICT_TIMEOUT", "60")
         groups.append((nranks, [exe, "--testfile", paths[-1]], 900, env))
     try:
-        all_logs = run_binary_groups(groups, collect_errors=True)
-        for i, ((binary, nranks, lines, env), logs) in enumerate(zip(jobs, all_logs)):
-            text = str(logs) if isinstance(logs, AssertionError) else "\n".join(logs)
-            passed = not isinstance(logs, AssertionError) and " FAILED" not in logs[0] and "Passed all tests." in logs[0]
-            if not passed and any(sig in text for sig in _IPC_EXPORT_REFUSED):
-                print("%s (%d ranks): the runtime refused to export a fresh workspace over IPC (platform hiccup, see "
-                      "_IPC_EXPORT_REFUSED); one more attempt of this list, alone" % (binary, nranks))
-                all_logs[i] = run_binary_groups([groups[i]], collect_errors=True)[0]
+        all_logs = run_binary_groups(groups)
     finally:
         for p in paths:
             os.unlink(p)
     for (binary, nranks, lines, env), logs in zip(jobs, all_logs):
-        if isinstance(logs, AssertionError):
-            raise logs
         _check_logs(binary, lines, logs)
 
 

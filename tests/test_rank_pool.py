@@ -72,37 +72,43 @@ def test_fresh_processes_on_request_and_for_the_bodies_about_process_state():
         del os.environ[mp.POOL_SWITCH]
 
 
-def test_native_lists_get_one_more_attempt_for_a_refused_ipc_export_only(monkeypatch, capsys):
-    """tests/test_gpu_native.py::_run_side_by_side: a list whose failure carries the signature of the runtime refusing to export a
-    fresh workspace over IPC is run once more, alone, and says so; any other failure is raised as it is; nothing is repeated twice."""
-    from tests import test_gpu_native as N
-    good = ["command: x\n PASSED\nPassed all tests.\n"]
-    calls = []
-
-    def fake_groups(script):
-        def run(groups, max_ranks=8, collect_errors=False):
-            assert collect_errors
-            calls.append([(g[0], dict(g[3])) for g in groups])
-            return [script.pop(0) for _ in groups]
-        return run
-
-    monkeypatch.setattr(N, "_binary", lambda name: "/bin/true")
+def test_launches_get_one_more_attempt_for_a_refused_ipc_export_only(monkeypatch, capsys):
+    """tests/mp.py: a launch (native program or Python bodies) whose failure carries the signature of the runtime refusing to export
+    a fresh workspace over IPC is made once more, in new processes, and says so; any other failure is raised as it is; nothing
+    is repeated twice."""
     refused = AssertionError("rank 0 exit 1\nCUDECOMP:ERROR: ... (a peer rank could not export its buffer over IPC)\n FAILED")
-    # two lists side by side, the second one hits the platform error: only that one runs again, alone, and passes
-    monkeypatch.setattr(mp, "run_binary_groups", fake_groups([good, refused, good]))
-    N._run_side_by_side([("transpose_test_R64", 4, ["a"], None), ("halo_test_R64", 4, ["b"], {"X": "1"})])
-    assert [len(c) for c in calls] == [2, 1] and calls[1][0][1]["X"] == "1"
-    assert all(env["CUDECOMP_TEST_STOP_AT_FIRST_FAILURE"] == "1" for c in calls for _, env in c)
-    assert "one more attempt" in capsys.readouterr().out
-    # the second attempt fails as well: raised
-    del calls[:]
-    monkeypatch.setattr(mp, "run_binary_groups", fake_groups([refused, refused]))
-    with pytest.raises(AssertionError, match="could not export"):
-        N._run_side_by_side([("transpose_test_R64", 4, ["a"], None)])
-    assert len(calls) == 2
-    # another failure (a wrong cell): no second attempt
-    del calls[:]
-    monkeypatch.setattr(mp, "run_binary_groups", fake_groups([["command: x\n FAILED\nFailed 1/1 tests.\n"]]))
-    with pytest.raises(AssertionError):
-        N._run_side_by_side([("transpose_test_R64", 4, ["a"], None)])
-    assert len(calls) == 1
+    other = AssertionError("rank 0 exit 1\n FAILED\nFailed 1/1 tests.")
+    for launcher, once in (("run_binary_ranks", "_run_binary_ranks_once"), ("run_ranks", "_run_ranks_once")):
+        call = (lambda: mp.run_binary_ranks(4, ["/bin/true"], 10, {"X": "1"})) if launcher == "run_binary_ranks" else \
+               (lambda: mp.run_ranks(4, "tests.gpu_bodies", "pool_probe", {}, 10, {"X": "1"}))
+        for script, want_calls, raises in (([refused, ["ok"]], 2, None), ([refused, refused], 2, "could not export"),
+                                           ([other], 1, "Failed 1/1"), ([["ok"]], 1, None)):
+            calls = []
+
+            def fake(*a, **k):
+                calls.append(a)
+                r = script.pop(0)
+                if isinstance(r, AssertionError):
+                    raise r
+                return r
+
+            monkeypatch.setattr(mp, once, fake)
+            if raises:
+                with pytest.raises(AssertionError, match=raises):
+                    call()
+            else:
+                assert call() == ["ok"]
+            assert len(calls) == want_calls, (launcher, want_calls, calls)
+            out = capsys.readouterr().out
+            assert ("one more attempt" in out) == (want_calls == 2)
+    assert mp.pool_stats["second_attempts"] >= 4
+
+
+def test_native_case_lists_are_told_to_stop_at_their_first_failure(monkeypatch):
+    from tests import test_gpu_native as N
+    seen = []
+    monkeypatch.setattr(N, "_binary", lambda name: "/bin/true")
+    monkeypatch.setattr(mp, "run_binary_groups", lambda groups, **k: seen.extend(groups) or [["command: x\n PASSED\nPassed all tests.\n"]] * len(groups))
+    N._run_side_by_side([("transpose_test_R64", 4, ["a"], None), ("halo_test_R64", 4, ["b"], {"X": "1", "CUDECOMP_TEST_VERDICT_TIMEOUT": "5"})])
+    assert [g[3]["CUDECOMP_TEST_STOP_AT_FIRST_FAILURE"] for g in seen] == ["1", "1"]
+    assert [g[3]["CUDECOMP_TEST_VERDICT_TIMEOUT"] for g in seen] == ["60", "5"] and seen[1][3]["X"] == "1"
