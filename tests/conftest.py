@@ -231,3 +231,5 @@ def pytest_terminal_summary(terminalreporter):
     if st["started"] or st["fresh_launches"]:
         terminalreporter.write_line("rank launches: %d jobs on %d rank pool(s), %d launches of fresh processes"
                                     % (st["jobs"], st["started"], st["fresh_launches"]))
+    if st.get("second_attempts"):  # (tests/mp.py IPC_EXPORT_REFUSED: said here because the output of passing tests is not shown)
+        terminalreporter.write_line("launches repeated once because the runtime refused an IPC export: %d" % st["second_attempts"])
