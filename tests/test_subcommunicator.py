@@ -36,5 +36,6 @@ def test_handles_on_sub_communicators_see_their_group_only(n, group):
 def test_without_mpi_discovery_the_communicator_is_a_token_for_the_world():
     # the launcher-environment bootstrap (what a torchrun / ctypes harness gets) cannot express sub-communicators: with the
     # discovery switched off the same program sees the world and the group-sized grid is refused
-    rc, text = run(build(), 4, {"SUBCOMM_GROUP": "2", "CUDECOMP_DISABLE_MPI_DISCOVERY": "1"})
+    from tests.mp import free_port   # (a port of its own: the library's default port may be in use by something else on the machine)
+    rc, text = run(build(), 4, {"SUBCOMM_GROUP": "2", "CUDECOMP_DISABLE_MPI_DISCOVERY": "1", "CUDECOMP_BOOTSTRAP_PORT": str(free_port())})
     assert rc != 0 and "product of pdims values must equal number of ranks" in text, text
