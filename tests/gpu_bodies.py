@@ -121,6 +121,11 @@ def transpose_chain(rank, nranks, args):
         for name in args["expect_path"]:
             if counters[name] <= 0:
                 failures.append("executor path %r did not run: %r" % (name, counters))
+    if args.get("expect_counts"):   # exact counts of executor paths of this descriptor, e.g. {"rotations": 2}
+        counters = cd.cudecompExtGetCounters(h, gd)
+        for name, want in args["expect_counts"].items():
+            if counters[name] != want:
+                failures.append("executor path %r ran %d times, expected %d" % (name, counters[name], want))
     torch.cuda.synchronize()
     for p in to_free:
         cd.cudecompFree(h, gd, p)

@@ -159,6 +159,26 @@ def test_in_place_rotation_of_cubic_grids(kind):
     cd.cudecompGridDescDestroy(h, gd)
 
 
+def test_in_place_rotation_under_every_triple_of_memory_orders():
+    """Cubic single-rank grids IN PLACE under all 216 triples of memory orders (X, Y and Z pencils independently): a hop runs the
+    in-place rotation kernel exactly where the planner says the two orders are a rotation of each other (the CPU planner's word,
+    cudecompExtPlanTranspose(...).rotate, against the executor's counter), the staged form everywhere else, and every hop of every
+    chain matches the oracle.  fp64 and complex128, two tiles per edge (432 chains in well under a second)."""
+    import itertools
+    perms = list(itertools.permutations((0, 1, 2)))
+    triples = list(itertools.product(perms, perms, perms))
+    rotated = 0
+    for kind, n, step in ((1, 32, 1), (3, 16, 1)):
+        for mo in triples[::step]:
+            spec = cd.make_grid_spec((n, n, n), (1, 1), [list(o) for o in mo])
+            want = sum(1 for op in cd.OPS if cd.cudecompExtPlanTranspose(spec, 0, op, inplace=True).rotate != 0)
+            rotated += want
+            args = {"gdims": (n, n, n), "pdims": (1, 1), "mem_order": mo, "kind": kind, "out_of_place": [False],
+                    "expect_counts": {"rotations": want}}
+            assert B.transpose_chain(0, 1, args) == [], mo
+    assert rotated > 100   # (a third of the order pairs are rotations of each other)
+
+
 def test_more_than_2_31_elements_per_pencil_every_cell():
     """Maximum-size edge, every cell: 2048 x 1024 x 1056 fp32 = 2.2e9 elements (> 2^31) in one pencil, each hop compared
     on the device with the closed form (low 31 bits of the global linear index, which itself exceeds 2^31)."""
