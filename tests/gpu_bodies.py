@@ -443,7 +443,7 @@ def graph_cycle(rank, nranks, args):
     failures = []
 
     def cycle(sptr):
-        cur, nxt = a, b
+        cur, nxt = (a, a) if args.get("in_place") else (a, b)   # in_place: every hop on the one buffer
         for op in cd.OPS:
             cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DTYPE_OF_KIND[kind], stream=sptr)
             if op == "YToZ":

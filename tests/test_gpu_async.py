@@ -35,3 +35,14 @@ def test_whole_cycle_in_one_user_graph(backend, n, pdims):
     args = {"gdims": (96, 80, 112), "pdims": pdims, "kind": 1, "ac": (1, 1, 1), "transpose_backend": backend, "replays": 3}
     for r in run_ranks(n, "tests.gpu_bodies", "graph_cycle", args, timeout=300):
         assert r["failures"] == []
+
+
+@pytest.mark.parametrize("gdims,rotations", [((64, 64, 64), 8), ((64, 64, 48), 0)], ids=["cubic_rotation_kernel", "staged"])
+def test_in_place_cycle_of_one_rank_in_one_user_graph(gdims, rotations):
+    """Single rank, IN PLACE, captured in the caller's hipGraph and replayed on fresh data: the cubic grid runs the in-place
+    rotation kernel (csrc/kernels_rotate.hip: 4 hops x (warm-up + capture); replays launch no library code), the other one the
+    staged form (permute into the workspace, copy back); X and Z pencils of every replay checked cell by cell."""
+    args = {"gdims": gdims, "pdims": (1, 1), "kind": 1, "ac": (1, 1, 1), "replays": 3, "in_place": True}
+    for r in run_ranks(1, "tests.gpu_bodies", "graph_cycle", args, timeout=300):
+        assert r["failures"] == []
+        assert r["counters"]["rotations"] == rotations, r["counters"]
