@@ -611,7 +611,7 @@ def perf_report(rank, nranks, args):
     a = torch.zeros(nel * es, dtype=torch.uint8, device="cuda")
     b = torch.zeros(nel * es, dtype=torch.uint8, device="cuda")
     for _ in range(args.get("repeat", 4)):
-        cur, nxt = a, b
+        cur, nxt = (a, a) if args.get("in_place") else (a, b)
         for op in cd.OPS:
             cd.cudecompTranspose(op, h, gd, cur.data_ptr(), nxt.data_ptr(), work, cd.DTYPE_OF_KIND[kind], None, None,
                                  None, None, G.stream_ptr())
@@ -620,6 +620,7 @@ def perf_report(rank, nranks, args):
             cd.cudecompUpdateHalos(axis, h, gd, a.data_ptr(), work, cd.DTYPE_OF_KIND[kind], halo, (True, True, True),
                                    dim, None, G.stream_ptr())
     torch.cuda.synchronize()
+    counters = cd.cudecompExtGetCounters(h, gd)
     cd.cudecompFree(h, gd, work)
     cd.cudecompGridDescDestroy(h, gd)  # collective; rank 0 prints the report and writes the CSV files
     files = {}
@@ -627,7 +628,7 @@ def perf_report(rank, nranks, args):
         for f in sorted(glob.glob(os.path.join(outdir, "*.csv"))):
             with open(f) as fh:
                 files[os.path.basename(f)] = fh.read()
-    return {"files": files}
+    return {"files": files, "counters": counters}
 
 
 def repeated_cycle(rank, nranks, args):

@@ -44,3 +44,24 @@ def test_performance_report_csv(nranks, pdims):
     hhead = [i for i, line in enumerate(hal) if not line.startswith("#")][0]
     assert hal[hhead] == "operation,dtype,dim,halo_extent,periods,padding,managed,samples,total_ms,SR_ms,local_ms,SR_BW_GBps"
     assert [line.split(",")[0:3] for line in hal[hhead + 1:]] == [["HaloX", "D", "1"], ["HaloY", "D", "2"]]
+
+
+def test_performance_report_of_in_place_rotations():
+    """Single rank, cubic, in place: the hops are in-place rotation kernels (csrc/kernels_rotate.hip), and the report has them as
+    in-place rows (inplace = T) with their samples and a local time."""
+    outdir = tempfile.mkdtemp(prefix="cudecomp_perf_")
+    env = {"CUDECOMP_ENABLE_PERFORMANCE_REPORT": "1", "CUDECOMP_PERFORMANCE_REPORT_DETAIL": "2",
+           "CUDECOMP_PERFORMANCE_REPORT_SAMPLES": "4", "CUDECOMP_PERFORMANCE_REPORT_WARMUP_SAMPLES": "1",
+           "CUDECOMP_PERFORMANCE_REPORT_WRITE_DIR": outdir}
+    args = {"gdims": (64, 64, 64), "pdims": (1, 1), "ac": K.ALL_AC, "kind": 1, "repeat": 4, "in_place": True}
+    res = run_ranks(1, "tests.gpu_bodies", "perf_report", args, timeout=600, extra_env=env)
+    assert res[0]["counters"]["rotations"] == 16, res[0]["counters"]
+    files = res[0]["files"]
+    name = [f for f in files if f.startswith("cudecomp-perf-report-transpose-aggregated-")]
+    assert len(name) == 1, sorted(files)
+    agg = files[name[0]].splitlines()
+    head = [i for i, line in enumerate(agg) if not line.startswith("#")][0]
+    rows = [line.rsplit(",", 7) for line in agg[head + 1:]]
+    assert [r[0].split(",")[0] for r in rows] == ["TransposeXY", "TransposeYZ", "TransposeZY", "TransposeYX"]
+    for r in rows:   # ..., inplace, managed, samples, total_ms, A2A_ms, local_ms, A2A_BW_GBps
+        assert r[1] == "T" and r[2] == "F" and r[3] == "3" and float(r[4]) > 0 and float(r[6]) > 0, r
