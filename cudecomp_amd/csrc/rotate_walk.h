@@ -20,6 +20,9 @@ namespace cudecomp {
 // the bits that choose the L2 channel inside an XCD and the HBM channel behind it.  With b0 = w % nb an XCD would see an eighth of
 // the b0 values and ONE value of b1 and of b2 for thousands of consecutive workgroups: 0.56 of the HBM peak at 1024^3 fp64, 0.50
 // for complex128; per XCD with shears 0.64 / 0.62 (profiles/r06_tuning.md section 8: 265 walks, the best dozen within 1 %).
+// Measured beside it (TCC_REQ per XCC, profiles/r06_rotate_l2_requests_per_xcc.json): with b0 = w % nb the XCDs do not get the same
+// amount of work either -- owners are the triples whose b2 is the smallest, so they are denser at large b0, and XCD x only sees
+// b0 = x mod 8: XCD 7 serves 8 % more than the mean, XCD 0 9 % less; the per-XCD walk is level within 0.7 %.
 constexpr int kRotateWalk = 15 | 1 << 4 | 3 << 8 | 2 << 12;
 
 // the walk as launched for nb blocks per edge: the cube edge never exceeds the array
